@@ -1,0 +1,23 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (plain PyTorch fp32 / fp16-on-CPU) of the reference's hybrid
+FSDP + frame-chunked denoising path
+(`Distribution/strategies/fsdp_chunked_coherent.py`) and of the diffusers
+operators that path calls (`UNet3DConditionModel`, `DDIMScheduler`).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import anything from this package, and only as the checker / the reported
+CPU baseline.  Nothing under the product package imports it; the product path
+raises when the HIP library is missing.
+
+PARITY UNPINNED at the diffusers boundary: `diffusers` is not installed in the
+build container, is not vendored under /root/reference, and the reference
+holds no test, fixture or golden vector for any UNet / scheduler / blended
+latent result.  What *is* pinned:
+  * planner / blend / noise semantics — hand-executed known-answer tables from
+    the reference source (tests/test_oracle_planner.py, test_oracle_blend.py)
+    plus the one committed notebook known answer
+    (`Distribution/legacy/Latent Chunking/latent_chunking.ipynb:173-176`);
+  * the UNet structure — total parameter count 1 411 233 860, per-block totals
+    and the diffusers state-dict key/shape table (tests/test_oracle_unet.py).
+"""

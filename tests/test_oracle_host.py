@@ -1,0 +1,110 @@
+"""Pins the oracle's orchestration restatement against known answers hand-executed from the
+reference source and the one committed notebook known answer."""
+import pytest
+import torch
+
+from oracle.ddim_ref import DDIMSchedulerRef
+from oracle.pipeline_ref import (PlannerHang, base_noise, global_context, my_ranges, plan_chunks,
+                                 ramp_blend)
+
+# (T, world, chunk_size, overlap, no_chunking, rule) -> (cs, ov, ranges)
+PLANNER_KATS = [
+    # cfg1: chunk_only rule, T=8, W=1  (chunk_only.py:80-105)
+    ((8, 1, 0, 4, False, "third"), (8, 2, [(0, 8), (6, 8)])),
+    # cfg2/3 --mode fsdp: every rank denoises the full clip (fsdp_chunked_coherent.py:150,174-177)
+    ((24, 1, 0, 4, True, "coherent"), (24, 0, [(0, 24)])),
+    ((24, 2, 0, 4, True, "coherent"), (24, 0, [(0, 24), (0, 24)])),
+    # cfg3-hybrid
+    ((24, 2, 0, 4, False, "coherent"), (16, 4, [(0, 16), (12, 24)])),
+    # cfg4
+    ((48, 4, 0, 4, False, "coherent"), (16, 4, [(0, 16), (12, 28), (24, 40), (36, 48)])),
+    # cfg5
+    ((96, 8, 0, 4, False, "coherent"),
+     (16, 4, [(0, 16), (12, 28), (24, 40), (36, 52), (48, 64), (60, 76), (72, 88), (84, 96)])),
+    # script default T=32, W=1
+    ((32, 1, 0, 4, False, "coherent"), (16, 4, [(0, 16), (12, 28), (24, 32)])),
+]
+
+
+@pytest.mark.parametrize("args,want", PLANNER_KATS)
+def test_planner_kat(args, want):
+    assert plan_chunks(*args) == want
+
+
+def test_planner_T32_W3():
+    cs, ov, ranges = plan_chunks(32, 3, 0, 4, False, "coherent")
+    assert cs == 10 and ov == 4 and len(ranges) == 6 and ranges[-1] == (30, 32)
+    assert len(ranges) % 3 == 0
+
+
+def test_planner_notebook_known_answer():
+    # Distribution/legacy/Latent Chunking/latent_chunking.ipynb:173-176 — 16 frames, chunk 8, overlap 2
+    _, _, ranges = plan_chunks(16, 1, 8, 2, False, "coherent")
+    assert ranges == [(0, 8), (6, 14), (12, 16)]
+
+
+def test_planner_hang_is_an_error():
+    # T=24, world=8, default overlap 4 -> cs=3 <= ov: the reference loops forever
+    with pytest.raises(PlannerHang):
+        plan_chunks(24, 8, 0, 4, False, "coherent")
+
+
+def test_round_robin_assignment():
+    _, _, ranges = plan_chunks(96, 8, 0, 4)
+    for r in range(8):
+        assert my_ranges(ranges, 8, r) == [ranges[r]]
+    _, _, ranges = plan_chunks(32, 3, 0, 4)
+    assert my_ranges(ranges, 3, 1) == [ranges[1], ranges[4]]
+
+
+def test_ddim_timesteps_and_alphas():
+    s = DDIMSchedulerRef()
+    s.set_timesteps(50)
+    ts = s.timesteps.tolist()
+    assert ts[0] == 981 and ts[1] == 961 and ts[-1] == 1 and len(ts) == 50
+    s.set_timesteps(10)
+    assert s.timesteps.tolist() == [901, 801, 701, 601, 501, 401, 301, 201, 101, 1]
+    # scaled-linear betas: a_bar[0] = 1 - 0.00085
+    assert abs(float(s.alphas_cumprod[0]) - (1 - 0.00085)) < 1e-7
+    assert 0.0046 < float(s.alphas_cumprod[-1]) < 0.0048       # SD-family terminal a_bar
+    # last step uses final_alpha_cumprod = a_bar[0] (set_alpha_to_one False)
+    s1, sa, sp, s1p = s.coefficients(1)
+    assert abs(float(sp) ** 2 - float(s.alphas_cumprod[0])) < 1e-7
+
+
+def test_ddim_step_inverts_forward_noising():
+    s = DDIMSchedulerRef()
+    s.set_timesteps(50)
+    x0 = torch.randn(1, 4, 3, 8, 8)
+    eps = torch.randn_like(x0)
+    t = 501
+    a = s.alphas_cumprod[t]
+    xt = a.sqrt() * x0 + (1 - a).sqrt() * eps
+    out = s.step(eps, t, xt)
+    assert torch.allclose(out.pred_original_sample, x0, atol=1e-5)
+    ap = s.alphas_cumprod[t - 20]
+    assert torch.allclose(out.prev_sample, ap.sqrt() * x0 + (1 - ap).sqrt() * eps, atol=1e-5)
+
+
+def test_ctx_is_frame_mean_of_base_noise():
+    base = base_noise(6, 4, 8, 8)
+    ctx = global_context(6, 4, 8, 8)
+    assert ctx.shape == (1, 4, 1, 8, 8) and ctx.dtype == torch.float16
+    assert torch.equal(ctx, base.mean(dim=2, keepdim=True))
+
+
+def test_blend_weights_kat():
+    # ov=4: chunk weights [0,1/3,2/3,1,...,1,2/3,1/3,0]; frames 0 and T-1 end at exactly 0
+    T, ov = 24, 4
+    like = torch.zeros(1, 1, T, 1, 1, dtype=torch.float16)
+    ones = lambda s, e: (s, e, torch.ones(1, 1, e - s, 1, 1, dtype=torch.float16))
+    out = ramp_blend([ones(0, 16), ones(12, 24)], T, ov, like)
+    assert out.dtype == torch.float32
+    v = out.flatten()
+    assert v[0] == 0 and v[T - 1] == 0                       # reference quirk
+    assert torch.allclose(v[1:T - 1], torch.ones(T - 2), atol=2e-3)
+    # cfg1: chunk (6,8) gets w=[1,0] (second assignment overrides the first)
+    out = ramp_blend([ones(0, 8), ones(6, 8)], 8, 2, torch.zeros(1, 1, 8, 1, 1, dtype=torch.float16))
+    v = out.flatten()
+    # chunk0 w = [0,1,1,1,1,1,1,0]; chunk1 w = [1,0] -> frame 6: (1+1)/2, frame 7: 0/1e-6 = 0
+    assert v[0] == 0 and v[7] == 0 and abs(float(v[6]) - 1.0) < 1e-3
