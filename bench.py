@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — denoising-step throughput of the HIP path on Zeroscope-XL shapes (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* = one iteration of `fsdp_chunked_coherent.py:132-142` for the chunk a rank owns:
+cat/ctx-inject -> UNet3D forward on the CFG batch of 2 -> guidance combine -> DDIM update.
+N=1 : BASELINE config[1] — Zeroscope-XL, 24 frames @ 576x1024 (latent 72x128), monolithic.
+N>1 : weak scaling over frame chunks — a (20*N+4)-frame video planned with chunk 24 / overlap 4
+      gives exactly N 24-frame windows, one per rank (reference planner + round-robin, :149-184);
+      no data-path collective inside the step; ctx broadcast before and chunk gather after the
+      loop are outside the timed steps.  value = N * steps / max-over-ranks time.
+Weights are synthetic (diffusers-shaped, seeded); inputs are synthetic noise/text embeddings.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TFLOP_PER_STEP_24F = 156.97      # algorithmic FLOPs of one CFG step at 24 f, XL
+PEAK_MFMA_TFLOPS = 2500.0        # gfx950 dense fp16/bf16 matrix peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(frames: int, threads: int):
+    """Oracle (fp32 PyTorch-CPU restatement, kind "port") timed on this host on a bounded sample:
+    one CFG UNet forward with XL-shaped weights at `frames` frames @ 576x1024; FLOPs are linear in
+    the frame count, so the 24-frame rate is sample_time * 24/frames."""
+    from oracle.unet3d_ref import UNet3DConditionModelRef, UNet3DConfig
+    torch.set_num_threads(threads)
+    with torch.device("meta"):
+        m = UNet3DConditionModelRef(UNet3DConfig.zeroscope())
+    m = m.to_empty(device="cpu").eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_(0.0, 0.02)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, frames, 72, 128, generator=g)
+    e = torch.randn(2, 77, 1024, generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        m(x, torch.tensor(981), e)
+    dt = time.time() - t0
+    return {"value": round(1.0 / (dt * 24.0 / frames), 6), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 torch-CPU UNet3D, XL widths, 1 CFG forward at {frames} of 24 frames @576x1024 "
+                      f"({dt:.1f} s), scaled x{24 // frames} to the 24-frame step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=24, help="frames per chunk (default: BASELINE 24)")
+    ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vdx  # noqa: F401
+    from vdx import ops
+    from vdx.pipeline import seeded_noise
+    from vdx.planner import plan
+    from vdx.scheduler import DDIMScheduler
+    from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
+    from vdx.weights import synthetic_state_dict
+
+    F, H, W = args.frames, 72, 128
+    cfg = UNet3DConfig.zeroscope()
+    unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
+    sched = DDIMScheduler()
+    sched.set_timesteps(50, device=dev)
+    if world == 1:
+        T, ranges, ctx = F, [(0, F)], None
+        workload = f"Zeroscope_v2_XL UNet3D, {F} frames @576x1024 (latent {H}x{W}), CFG batch 2, monolithic, 1 GPU"
+    else:
+        T = (F - 4) * world + 4
+        cp = plan(T, world, chunk_size=F, overlap=4)
+        ranges = cp.for_rank(rank)
+        assert len(ranges) == 1 and ranges[0][1] - ranges[0][0] == F, (cp, ranges)
+        workload = (f"Zeroscope_v2_XL UNet3D, {T}-frame video as {world} windows of {F} frames (chunk {F}, overlap 4, "
+                    f"hybrid_ctx), one window per GPU, CFG batch 2")
+    base = seeded_noise((1, 4, T, H, W), sched.init_noise_sigma, dev)
+    if world > 1:
+        ctx = base.mean(dim=2, keepdim=True).contiguous()
+        dist.broadcast(ctx, src=0)
+    s, e = ranges[0]
+    lat = base[:, :, s:e].clone()
+    torch.manual_seed(1)
+    emb = torch.randn(2, 77, 1024, device=dev, dtype=torch.float16)
+    ts = sched._host_timesteps
+
+    def step(i, lat):
+        t = ts[i % len(ts)]
+        x = ops.cfg_input(lat, ctx, 0.35)
+        noise = unet(x, t, encoder_hidden_states=emb).sample
+        return sched.step_cfg(noise, t, lat, 7.5)
+
+    for i in range(args.warmup):
+        lat = step(i, lat)
+    torch.cuda.reset_peak_memory_stats()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prof = None if args.no_profile else []
+    ops.PROFILE = prof
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lat = step(args.warmup + i, lat)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.PROFILE = None
+    finite = bool(torch.isfinite(lat.float()).all())
+    peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
+    tt = torch.tensor([dt, peak_gb], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, peak_gb = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        tf_step = TFLOP_PER_STEP_24F * F / 24.0
+        sps = world * args.steps / dt
+        out = {
+            "metric": "denoising steps/sec, Zeroscope-XL 24f@1024x576 (CFG UNet3D forward + guidance + DDIM)",
+            "value": round(sps, 5), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": workload, "frames_per_gpu": F, "scheduler": "DDIM-50", "guidance_scale": 7.5},
+            "peak_hbm_gb_per_gpu": round(peak_gb, 3),
+            "path_tflops_per_gpu": round(tf_step * args.steps / dt, 2),
+            "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
+            "output_finite": finite,
+        }
+        if prof:
+            torch.cuda.synchronize()
+            agg = {}
+            for name, flops, e0, e1 in prof:
+                a = agg.setdefault(name, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += e0.elapsed_time(e1)
+                a[2] += 1
+            name, (fl, ms, n) = max(agg.items(), key=lambda kv: kv[1][1])
+            ach = fl / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None, "kernel": name,
+                               "launches": n, "avg_launch_ms": round(ms / n, 4),
+                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}
+            out["gemm_kernels"] = {k: {"launches": v[2], "ms": round(v[1], 2), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
+                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+            out["gemm_ms_per_step"] = round(sum(v[1] for v in agg.values()) / args.steps, 2)
+        else:
+            ach = tf_step * args.steps / dt
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None, "kernel": "whole step"}
+        if world == 1 and args.cpu_frames > 0:
+            del unet
+            torch.cuda.empty_cache()
+            ncpu = min(len(os.sched_getaffinity(0)), 16)      # the 1-GPU box's CPU share
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, ncpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""ctypes binding of libvdx_hip.so (C-ABI declared in include/vdx.h).
+
+The product path has no CPU fallback: if the library is missing or a symbol is absent,
+loading raises.  Nothing here imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdx_hip.so")
+
+
+class GemmArgs(C.Structure):
+    """Mirror of `vdx_gemm_args` (include/vdx.h)."""
+    _fields_ = [
+        ("a", C.c_void_p), ("a2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("bias2", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32),
+        ("c1", C.c_int32), ("c2", C.c_int32),
+        ("lda", C.c_int32), ("lda2", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
+        ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
+        ("stride", C.c_int32), ("upsample", C.c_int32), ("frames", C.c_int32), ("hw", C.c_int32),
+        ("rows_per_bias2", C.c_int32), ("ldb2", C.c_int32), ("epilogue", C.c_int32),
+    ]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/vdx.h declares
+SIGNATURES = {
+    "vdx_last_error": (C.c_char_p, []),
+    "vdx_version": (_i, []),
+    "vdx_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
+    "vdx_conv_in_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vdx_rows_to_ncfhw_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vdx_silu_f16": (_i, [_vp, _vp, _sz, _vp]),
+    "vdx_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
+    "vdx_groupnorm_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "vdx_layernorm_f16": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
+    "vdx_flash_attn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "vdx_temporal_attn_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "vdx_cfg_input_f16": (_i, [_vp, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "vdx_cfg_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),
+    "vdx_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _sz, _vp]),
+    "vdx_blend_accumulate_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vdx_blend_finalize_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class VdxError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly when it is not built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VdxError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the denoising path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().vdx_last_error()
+        raise VdxError(f"{what}: {msg.decode() if msg else 'error'} (rc={rc})")

@@ -1,0 +1,220 @@
+// elementwise.hip — layout edges of the UNet (conv_in / output permute), SiLU, and the
+// orchestration ops the reference owns: ctx injection (fsdp_chunked_coherent.py:133-137),
+// CFG combine + DDIM step (:141-142), linear-ramp blend (:204-217).
+// The orchestration kernels round to fp16 after every tensor op, in the order torch evaluates
+// the reference's expressions, so they are bit-exact against the CPU oracle.
+#include "vdx_common.h"
+
+// ---- conv_in: Conv2d(Cin -> Cout, 3x3, pad 1) straight from the (B,Cin,F,H,W) latent ---------
+__global__ void conv_in_kernel(const f16* x, const f16* w, const f16* bias, f16* out, int B, int Cin,
+                               int F, int H, int W, int Cout) {
+    extern __shared__ f16 ws[];  // [Cout][9*Cin]
+    const int K = 9 * Cin;
+    for (int i = threadIdx.x; i < Cout * K; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    const int nvec = Cout >> 3;
+    const long long total = (long long)B * F * H * W * nvec;
+    const int HW = H * W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % nvec);
+        const long long pix = idx / nvec;
+        const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+        const int f = (int)((pix / HW) % F), b = (int)(pix / ((long long)HW * F));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bias ? (float)bias[cv * 8 + j] : 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = yy + ky - 1;
+            if ((unsigned)y >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xq = xx + kx - 1;
+                if ((unsigned)xq >= (unsigned)W) continue;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float v = (float)x[(((size_t)b * Cin + ci) * F + f) * HW + y * W + xq];
+                    const int k = (ky * 3 + kx) * Cin + ci;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v * (float)ws[(cv * 8 + j) * K + k];
+                }
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)acc[j];
+        *(f16x8*)(out + (size_t)pix * Cout + cv * 8) = o;
+    }
+}
+
+extern "C" int vdx_conv_in_f16(const void* x, const void* w, const void* bias, void* out, int B, int Cin,
+                               int F, int H, int W, int Cout, vdx_stream_t stream) {
+    VDX_CHECK(x && w && out, "conv_in: null pointer");
+    VDX_CHECK(B > 0 && Cin > 0 && F > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv_in: bad shape");
+    const size_t lds = (size_t)Cout * 9 * Cin * sizeof(f16);
+    VDX_CHECK(lds <= 64 * 1024, "conv_in: weights (%zu B) exceed the LDS budget", lds);
+    const long long total = (long long)B * F * H * W * (Cout / 8);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_in_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const f16*)x,
+                       (const f16*)w, (const f16*)bias, (f16*)out, B, Cin, F, H, W, Cout);
+    return vdx_launch_status("vdx_conv_in_f16");
+}
+
+// ---- rows [B*F*HW][ld] -> (B,C,F,H,W) -------------------------------------------------------
+__global__ void rows_to_ncfhw_kernel(const f16* rows, int ld, f16* out, int B, int C, int F, int HW) {
+    const long long total = (long long)B * C * F * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % HW);
+        const int f = (int)((idx / HW) % F);
+        const int c = (int)((idx / ((long long)HW * F)) % C);
+        const int b = (int)(idx / ((long long)HW * F * C));
+        out[idx] = rows[(((size_t)b * F + f) * HW + p) * ld + c];
+    }
+}
+
+extern "C" int vdx_rows_to_ncfhw_f16(const void* rows, int ld, void* out, int B, int C, int F, int H, int W,
+                                     vdx_stream_t stream) {
+    VDX_CHECK(rows && out && B > 0 && C > 0 && F > 0 && H > 0 && W > 0 && ld >= C, "rows_to_ncfhw: bad arguments");
+    const long long total = (long long)B * C * F * H * W;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(rows_to_ncfhw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)rows, ld,
+                       (f16*)out, B, C, F, H * W);
+    return vdx_launch_status("vdx_rows_to_ncfhw_f16");
+}
+
+// ---- SiLU (time-embedding MLP) --------------------------------------------------------------
+__global__ void silu_kernel(const f16* x, f16* y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (f16)silu_f((float)x[i]);
+}
+extern "C" int vdx_silu_f16(const void* x, void* y, size_t n, vdx_stream_t stream) {
+    VDX_CHECK(x && y && n > 0, "silu: bad arguments");
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(silu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, n);
+    return vdx_launch_status("vdx_silu_f16");
+}
+
+// ---- fsdp_chunked_coherent.py:133-137 -------------------------------------------------------
+//   x = cat([lat]*2);  x = x + context_weight * ctx.repeat(1,1,F,1,1)
+__global__ void cfg_input_kernel(const f16* lat, const f16* ctx, float weight, f16* x2, int C, int F, int HW) {
+    const size_t n = (size_t)C * F * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        f16 v = lat[i];
+        if (ctx) {
+            const int p = (int)(i % HW);
+            const int c = (int)(i / ((size_t)HW * F));
+            const f16 t = (f16)__fmul_rn((float)ctx[(size_t)c * HW + p], weight);  // fp16(cw * ctx)
+            v = (f16)__fadd_rn((float)v, (float)t);                                 // fp16(x + t)
+        }
+        x2[i] = v;
+        x2[n + i] = v;
+    }
+}
+extern "C" int vdx_cfg_input_f16(const void* lat, const void* ctx, float weight, void* x2, int C, int F, int HW,
+                                 vdx_stream_t stream) {
+    VDX_CHECK(lat && x2 && C > 0 && F > 0 && HW > 0, "cfg_input: bad arguments");
+    const size_t n = (size_t)C * F * HW;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cfg_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)lat,
+                       (const f16*)ctx, weight, (f16*)x2, C, F, HW);
+    return vdx_launch_status("vdx_cfg_input_f16");
+}
+
+// ---- fsdp_chunked_coherent.py:141-142 -------------------------------------------------------
+//   u, c = noise.chunk(2);  lat = sched.step(u + gs*(c-u), t, lat).prev_sample     (DDIM, eta 0)
+// DDIMScheduler.step with fp32 0-d coefficients and fp16 tensors: every tensor op rounds to fp16.
+__global__ void cfg_ddim_kernel(const f16* eps2, const f16* lat, f16* out, float gs, float s1, float sa,
+                                float sp, float s1p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float u = (float)eps2[i], c = (float)eps2[n + i], x = (float)lat[i];
+        const f16 t1 = (f16)__fsub_rn(c, u);                 // c - u
+        const f16 t2 = (f16)__fmul_rn(gs, (float)t1);        // gs * (c - u)
+        const f16 g = (f16)__fadd_rn(u, (float)t2);          // u + gs*(c-u)
+        const f16 a1 = (f16)__fmul_rn(s1, (float)g);         // sqrt(1-a_t) * eps
+        const f16 a2 = (f16)__fsub_rn(x, (float)a1);         // sample - ...
+        const f16 x0 = (f16)__fdiv_rn((float)a2, sa);        // / sqrt(a_t)
+        const f16 d = (f16)__fmul_rn(s1p, (float)g);         // sqrt(1-a_prev) * eps
+        const f16 b1 = (f16)__fmul_rn(sp, (float)x0);        // sqrt(a_prev) * x0
+        out[i] = (f16)__fadd_rn((float)b1, (float)d);
+    }
+}
+extern "C" int vdx_cfg_ddim_step_f16(const void* eps2, const void* lat, void* lat_out, float guidance,
+                                     float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev,
+                                     float sqrt_one_minus_aprev, size_t n, vdx_stream_t stream) {
+    VDX_CHECK(eps2 && lat && lat_out && n > 0, "cfg_ddim_step: bad arguments");
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)eps2,
+                       (const f16*)lat, (f16*)lat_out, guidance, sqrt_one_minus_at, sqrt_at, sqrt_aprev,
+                       sqrt_one_minus_aprev, n);
+    return vdx_launch_status("vdx_cfg_ddim_step_f16");
+}
+
+// DDIMScheduler.step alone (the reference's `sched.step(eps, t, lat).prev_sample`, :142), same
+// rounding chain; used when the CFG combine was done by the caller (unchanged reference script).
+__global__ void ddim_kernel(const f16* eps, const f16* lat, f16* out, float s1, float sa, float sp, float s1p,
+                            size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = (float)eps[i], x = (float)lat[i];
+        const f16 a1 = (f16)__fmul_rn(s1, g);
+        const f16 a2 = (f16)__fsub_rn(x, (float)a1);
+        const f16 x0 = (f16)__fdiv_rn((float)a2, sa);
+        const f16 d = (f16)__fmul_rn(s1p, g);
+        const f16 b1 = (f16)__fmul_rn(sp, (float)x0);
+        out[i] = (f16)__fadd_rn((float)b1, (float)d);
+    }
+}
+extern "C" int vdx_ddim_step_f16(const void* eps, const void* lat, void* lat_out, float sqrt_one_minus_at,
+                                 float sqrt_at, float sqrt_aprev, float sqrt_one_minus_aprev, size_t n,
+                                 vdx_stream_t stream) {
+    VDX_CHECK(eps && lat && lat_out && n > 0, "ddim_step: bad arguments");
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(ddim_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)eps,
+                       (const f16*)lat, (f16*)lat_out, sqrt_one_minus_at, sqrt_at, sqrt_aprev,
+                       sqrt_one_minus_aprev, n);
+    return vdx_launch_status("vdx_ddim_step_f16");
+}
+
+// ---- fsdp_chunked_coherent.py:204-217 -------------------------------------------------------
+//   full[:,:,s:e] += latc * w   (fp16 accumulator, fp32 product);  weight[:,:,s:e] += w
+__global__ void blend_acc_kernel(f16* full, float* weight, const f16* chunk, const float* w, int C, int T, int HW,
+                                 int s, int len) {
+    const size_t n = (size_t)C * len * HW;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < (size_t)len) weight[s + gid] = __fadd_rn(weight[s + gid], w[gid]);
+    for (size_t i = gid; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int f = (int)((i / HW) % len);
+        const int c = (int)(i / ((size_t)HW * len));
+        const size_t di = ((size_t)c * T + s + f) * HW + p;
+        const float prod = __fmul_rn((float)chunk[i], w[f]);
+        full[di] = (f16)__fadd_rn((float)full[di], prod);
+    }
+}
+extern "C" int vdx_blend_accumulate_f16(void* full, float* weight, const void* chunk, const float* w, int C, int T,
+                                        int HW, int s, int e, vdx_stream_t stream) {
+    VDX_CHECK(full && weight && chunk && w, "blend_accumulate: null pointer");
+    VDX_CHECK(C > 0 && T > 0 && HW > 0 && 0 <= s && s < e && e <= T, "blend_accumulate: bad range [%d,%d) of %d", s, e, T);
+    const int len = e - s;
+    const size_t n = (size_t)C * len * HW;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(blend_acc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (f16*)full, weight,
+                       (const f16*)chunk, w, C, T, HW, s, len);
+    return vdx_launch_status("vdx_blend_accumulate_f16");
+}
+
+//   lat = full / weight.clamp(min=1e-6)   -> fp32
+__global__ void blend_fin_kernel(const f16* full, const float* weight, float* out, int C, int T, int HW) {
+    const size_t n = (size_t)C * T * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)((i / HW) % T);
+        out[i] = __fdiv_rn((float)full[i], fmaxf(weight[t], 1e-6f));
+    }
+}
+extern "C" int vdx_blend_finalize_f32(const void* full, const float* weight, float* out, int C, int T, int HW,
+                                      vdx_stream_t stream) {
+    VDX_CHECK(full && weight && out && C > 0 && T > 0 && HW > 0, "blend_finalize: bad arguments");
+    const size_t n = (size_t)C * T * HW;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(blend_fin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)full, weight,
+                       out, C, T, HW);
+    return vdx_launch_status("vdx_blend_finalize_f32");
+}

@@ -1,0 +1,224 @@
+// norm.hip — GroupNorm (4-D and 5-D, optional 2-source concat, optional SiLU) and LayerNorm
+// over channels-last fp16 rows.  HBM-bound streaming kernels:
+//   GroupNorm = stats pass (1 read) + tiny finalize + apply pass (1 read + 1 write)
+//   LayerNorm = 1 read + 1 write, one wave per row, row cached in registers.
+// Thread mapping: a block owns a slab of rows of ONE sample; the block size is a multiple of
+// the number of 8-channel vectors per row, so every thread keeps a fixed channel vector
+// (coalesced 16-byte accesses, per-channel scale/shift held in registers).
+#include "vdx_common.h"
+
+#define GN_ROWS 128  // rows of one sample per block
+
+struct GnP {
+    const f16 *x, *x2;
+    int c1, c2, ldx, ldx2;
+    int C, G, cpg, nvec, krows;      // nvec = C/8, krows = rows processed in parallel per block
+    int n_samples, rps, nslabs;      // rps = rows per sample
+    float* partial;                  // [n_samples][nslabs][G][2]  (sum, sumsq)
+    float* ab;                       // [n_samples][C][2]          (scale, shift)
+};
+
+__device__ __forceinline__ f16x8 gn_load(const GnP& p, size_t row, int cv) {
+    const int c = cv * 8;
+    const f16* src = c < p.c1 ? p.x + row * p.ldx + c : p.x2 + row * p.ldx2 + (c - p.c1);
+    return *(const f16x8*)src;
+}
+
+__global__ void gn_partial_kernel(const GnP p) {
+    extern __shared__ float gsum[];  // [G][2]
+    const int tid = threadIdx.x;
+    const int sample = blockIdx.y, slab = blockIdx.x;
+    for (int i = tid; i < 2 * p.G; i += blockDim.x) gsum[i] = 0.f;
+    __syncthreads();
+    const int cv = tid % p.nvec, rsub = tid / p.nvec;
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+    const int r_end = min(p.rps, (slab + 1) * GN_ROWS);
+    for (int r = slab * GN_ROWS + rsub; r < r_end; r += p.krows) {
+        const f16x8 v = gn_load(p, (size_t)sample * p.rps + r, cv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[j];
+            s[j] += f;
+            ss[j] += f * f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (cv * 8 + j) / p.cpg;
+        atomicAdd(&gsum[2 * g], s[j]);
+        atomicAdd(&gsum[2 * g + 1], ss[j]);
+    }
+    __syncthreads();
+    float* dst = p.partial + ((size_t)sample * p.nslabs + slab) * 2 * p.G;
+    for (int i = tid; i < 2 * p.G; i += blockDim.x) dst[i] = gsum[i];
+}
+
+// one wave per (sample, group): combine slab partials in double, emit per-channel scale/shift
+__global__ void gn_finalize_kernel(const GnP p, const f16* gamma, const f16* beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int sg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (sg >= p.n_samples * p.G) return;
+    const int sample = sg / p.G, g = sg % p.G;
+    double s = 0.0, ss = 0.0;
+    for (int i = lane; i < p.nslabs; i += 64) {
+        const float* src = p.partial + ((size_t)sample * p.nslabs + i) * 2 * p.G + 2 * g;
+        s += (double)src[0];
+        ss += (double)src[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    const double n = (double)p.rps * p.cpg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int j = lane; j < p.cpg; j += 64) {
+        const int c = g * p.cpg + j;
+        const float a = rstd * (float)gamma[c];
+        float* dst = p.ab + ((size_t)sample * p.C + c) * 2;
+        dst[0] = a;
+        dst[1] = (float)beta[c] - (float)mean * a;
+    }
+}
+
+template <bool SILU>
+__global__ void gn_apply_kernel(const GnP p, f16* y, int ldy) {
+    const int tid = threadIdx.x;
+    const int sample = blockIdx.y, slab = blockIdx.x;
+    const int cv = tid % p.nvec, rsub = tid / p.nvec;
+    float a[8], b[8];
+    const float* ab = p.ab + ((size_t)sample * p.C + cv * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = ab[2 * j];
+        b[j] = ab[2 * j + 1];
+    }
+    const int r_end = min(p.rps, (slab + 1) * GN_ROWS);
+    for (int r = slab * GN_ROWS + rsub; r < r_end; r += p.krows) {
+        const size_t row = (size_t)sample * p.rps + r;
+        const f16x8 v = gn_load(p, row, cv);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * a[j] + b[j];
+            if (SILU) f = silu_f(f);
+            o[j] = (f16)f;
+        }
+        *(f16x8*)(y + row * ldy + cv * 8) = o;
+    }
+}
+
+static int gn_threads(int nvec, int* krows) {
+    int k = nvec >= 256 ? 1 : (256 + nvec - 1) / nvec;
+    *krows = k;
+    return k * nvec;
+}
+
+extern "C" size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G) {
+    const size_t nslabs = (rows_per_sample + GN_ROWS - 1) / GN_ROWS;
+    return ((size_t)n_samples * nslabs * G * 2 + (size_t)n_samples * C * 2) * sizeof(float);
+}
+
+extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
+                                 const void* gamma, const void* beta, float eps, int G,
+                                 int n_samples, int rows_per_sample, int silu, void* y, int ldy,
+                                 void* workspace, vdx_stream_t stream) {
+    VDX_CHECK(x && gamma && beta && y && workspace, "groupnorm: null pointer");
+    const int C = c1 + c2;
+    VDX_CHECK(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "groupnorm: c1=%d c2=%d must be multiples of 8", c1, c2);
+    VDX_CHECK((c2 == 0) == (x2 == nullptr), "groupnorm: x2/c2 mismatch");
+    VDX_CHECK(G > 0 && C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
+    VDX_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && (c2 == 0 || ldx2 % 8 == 0), "groupnorm: leading dims must be multiples of 8");
+    VDX_CHECK(n_samples > 0 && rows_per_sample > 0, "groupnorm: empty input");
+    VDX_CHECK(C / 8 <= 1024, "groupnorm: C=%d too wide", C);
+    GnP p;
+    p.x = (const f16*)x; p.x2 = (const f16*)x2; p.c1 = c1; p.c2 = c2; p.ldx = ldx; p.ldx2 = ldx2;
+    p.C = C; p.G = G; p.cpg = C / G; p.nvec = C / 8;
+    p.n_samples = n_samples; p.rps = rows_per_sample;
+    p.nslabs = (rows_per_sample + GN_ROWS - 1) / GN_ROWS;
+    p.partial = (float*)workspace;
+    p.ab = p.partial + (size_t)n_samples * p.nslabs * G * 2;
+    const int nt = gn_threads(p.nvec, &p.krows);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(p.nslabs, n_samples);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), 2 * G * sizeof(float), st, p);
+    const int nsg = n_samples * G;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, st, p, (const f16*)gamma, (const f16*)beta, eps);
+    if (silu)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(nt), 0, st, p, (f16*)y, ldy);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(nt), 0, st, p, (f16*)y, ldy);
+    return vdx_launch_status("vdx_groupnorm_f16");
+}
+
+// ---- LayerNorm: one wave per row, row cached in registers ---------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, int ldx, const f16* gamma, const f16* beta,
+                                                         float eps, int M, int C, f16* y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nvec = C >> 3;
+    const f16* xr = x + (size_t)row * ldx;
+    f16x8 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cv = lane + 64 * i;
+        if (cv < nvec) {
+            v[i] = *(const f16x8*)(xr + cv * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    f16* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cv = lane + 64 * i;
+        if (cv < nvec) {
+            const f16x8 g = *(const f16x8*)(gamma + cv * 8);
+            const f16x8 b = *(const f16x8*)(beta + cv * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[i][j] - mean) * rstd * (float)g[j] + (float)b[j]);
+            *(f16x8*)(yr + cv * 8) = o;
+        }
+    }
+}
+
+extern "C" int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps,
+                                 int M, int C, void* y, int ldy, vdx_stream_t stream) {
+    VDX_CHECK(x && gamma && beta && y, "layernorm: null pointer");
+    VDX_CHECK(M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "layernorm: bad shape M=%d C=%d", M, C);
+    const int nv = (C / 8 + 63) / 64;
+    VDX_CHECK(nv <= 4, "layernorm: C=%d too wide (max 2048)", C);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((M + 3) / 4), block(256);
+#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, (const f16*)x, ldx, (const f16*)gamma, (const f16*)beta, eps, M, C, (f16*)y, ldy)
+    switch (nv) {
+        case 1: LN_LAUNCH(1); break;
+        case 2: LN_LAUNCH(2); break;
+        case 3: LN_LAUNCH(3); break;
+        default: LN_LAUNCH(4); break;
+    }
+#undef LN_LAUNCH
+    return vdx_launch_status("vdx_layernorm_f16");
+}

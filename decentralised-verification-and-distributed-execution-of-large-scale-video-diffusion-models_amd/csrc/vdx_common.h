@@ -1,0 +1,61 @@
+// Shared device/host helpers for libvdx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/vdx.h"
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing ---------------------------------------------------------------------
+extern thread_local char g_vdx_err[512];
+static inline int vdx_fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_vdx_err, sizeof(g_vdx_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+#define VDX_CHECK(cond, ...)                      \
+    do {                                          \
+        if (!(cond)) return vdx_fail(__VA_ARGS__); \
+    } while (0)
+static inline int vdx_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vdx_fail("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// ---- device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// XCD-aware bijective remap of a linear block id (8 XCDs; blocks b and b+8 share an XCD):
+// gives every XCD a contiguous range of logical tiles so neighbouring tiles share its L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
+// 128 zero bytes per translation unit: padding taps / rows past the end read from here, so
+// gather loads stay unconditional (no exec-masked branches around loads).
+static __device__ __attribute__((aligned(128))) u32x4 g_zero_page[8];

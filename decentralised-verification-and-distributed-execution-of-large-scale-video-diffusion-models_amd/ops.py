@@ -1,0 +1,330 @@
+"""Host-side op wrappers: torch device tensors -> pointers/sizes -> libvdx_hip.so.
+
+Every wrapper validates shapes/strides/alignment on the host before a kernel is enqueued
+(a bad shape must raise here, never fault on the device).  Kernels run on torch's current
+HIP stream.  All tensors are fp16 CUDA(=HIP) tensors whose last dimension is contiguous;
+activations are channels-last row matrices [pixels][channels].
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, VdxError
+
+PLAIN, CONV3X3, TCONV3 = 0, 1, 2
+EPI_GEGLU = 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], name: str, dtype=torch.float16) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VdxError(f"{name}: expected a GPU tensor (the denoising path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise VdxError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise VdxError(f"{name}: last dimension must be contiguous")
+    if t.data_ptr() % 16 != 0:
+        raise VdxError(f"{name}: pointer not 16-byte aligned")
+    return t.data_ptr()
+
+
+def _rows(t: torch.Tensor, name: str):
+    if t.dim() != 2:
+        raise VdxError(f"{name}: expected a 2-D row matrix, got shape {tuple(t.shape)}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------------
+def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=0, residual=None,
+         out=None, geglu=False, conv=None, tconv=None):
+    """out[M][N] = epi(gather(a|a2)[M][K] @ w[N][K]^T).  See include/vdx.h `vdx_gemm_args`."""
+    lib = _lib.load()
+    ar, c1, lda = _rows(a, "a")
+    N, K = w.shape
+    if not w.is_contiguous():
+        raise VdxError("w: must be contiguous [N][K]")
+    c2 = 0
+    g = GemmArgs()
+    if a2 is not None:
+        a2r, c2, lda2 = _rows(a2, "a2")
+        g.lda2 = lda2
+    taps = {PLAIN: 1, CONV3X3: 9, TCONV3: 3}[mode]
+    if K != taps * (c1 + c2):
+        raise VdxError(f"gemm: K={K} != {taps}*(c1={c1}+c2={c2})")
+    n_out = N // 2 if geglu else N
+    # rows each operand must provide
+    if mode == PLAIN:
+        need_rows = M
+    elif mode == CONV3X3:
+        n_img, h_in, w_in, h_out, w_out, stride, ups = conv
+        if M != n_img * h_out * w_out:
+            raise VdxError(f"gemm: M={M} != n_img*h_out*w_out={n_img * h_out * w_out}")
+        need_rows = n_img * h_in * w_in
+        g.h_in, g.w_in, g.h_out, g.w_out, g.stride, g.upsample = h_in, w_in, h_out, w_out, stride, int(ups)
+    else:
+        frames, hw = tconv
+        if M % (frames * hw) != 0:
+            raise VdxError(f"gemm: M={M} is not a whole number of (frames={frames} x hw={hw}) clips")
+        need_rows = M
+        g.frames, g.hw = frames, hw
+    if ar < need_rows or (a2 is not None and a2r < need_rows):
+        raise VdxError(f"gemm: source has {ar} rows, kernel would read {need_rows}")
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=a.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < n_out:
+        raise VdxError(f"gemm: out {tuple(out.shape)} smaller than [{M}][{n_out}]")
+    if bias is not None and bias.numel() != N:
+        raise VdxError(f"gemm: bias has {bias.numel()} elements, N={N}")
+    if bias2 is not None:
+        b2r, b2c, ldb2 = _rows(bias2, "bias2")
+        if rows_per_bias2 <= 0 or b2r * rows_per_bias2 < M or b2c < N:
+            raise VdxError("gemm: bias2 does not cover M rows / N columns")
+        g.rows_per_bias2, g.ldb2 = rows_per_bias2, ldb2
+    if residual is not None:
+        rr, rc, ldr = _rows(residual, "residual")
+        if rr < M or rc < N:
+            raise VdxError(f"gemm: residual {tuple(residual.shape)} smaller than [{M}][{N}]")
+        g.ldr = ldr
+    g.a, g.a2, g.w = _p(a, "a"), _p(a2, "a2"), _p(w, "w")
+    g.bias, g.bias2, g.residual, g.out = _p(bias, "bias"), _p(bias2, "bias2"), _p(residual, "residual"), _p(out, "out")
+    g.M, g.N, g.K, g.mode, g.c1, g.c2 = M, N, K, mode, c1, c2
+    g.lda, g.ldo = lda, ldo
+    g.epilogue = EPI_GEGLU if geglu else 0
+    if PROFILE is None:
+        _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
+        return out
+    # bench.py instrumentation: HIP events on the launch stream around this one kernel
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
+    ev1.record()
+    PROFILE.append((gemm_kernel_name(N, mode, geglu), 2.0 * M * N * K, ev0, ev1))
+    return out
+
+
+PROFILE = None   # set to a list by bench.py to collect (kernel name, algorithmic FLOPs, start, end)
+
+
+def gemm_kernel_name(N: int, mode: int, geglu: bool) -> str:
+    """Name of the instantiation gemm.hip's pick_tile() launches (as rocprofv3 prints it)."""
+    tile = "128, 128, 2, 2" if N % 128 == 0 else "256, 64, 4, 1"
+    return f"gemm_kernel<{tile}, {0 if geglu else mode}, {'true' if geglu else 'false'}>"
+
+
+def conv_in(x, w, bias, out=None):
+    """x (B,Cin,F,H,W) fp16 -> rows [B*F*H*W][Cout]; w [Cout][3][3][Cin]."""
+    lib = _lib.load()
+    B, Cin, F, H, W = x.shape
+    if not x.is_contiguous():
+        raise VdxError("conv_in: x must be contiguous (B,C,F,H,W)")
+    Cout = w.shape[0]
+    if w.numel() != Cout * 9 * Cin or not w.is_contiguous():
+        raise VdxError("conv_in: w must be contiguous [Cout][3][3][Cin]")
+    if out is None:
+        out = torch.empty((B * F * H * W, Cout), dtype=torch.float16, device=x.device)
+    if out.shape[0] < B * F * H * W or out.shape[1] != Cout or not out.is_contiguous():
+        raise VdxError("conv_in: bad out")
+    _lib.check(lib.vdx_conv_in_f16(_p(x, "x"), _p(w, "w"), _p(bias, "bias"), _p(out, "out"),
+                                   B, Cin, F, H, W, Cout, _stream()), "vdx_conv_in_f16")
+    return out
+
+
+def rows_to_ncfhw(rows, B, C, F, H, W, out=None):
+    lib = _lib.load()
+    r, c, ld = _rows(rows, "rows")
+    if r < B * F * H * W or c < C:
+        raise VdxError("rows_to_ncfhw: rows too small")
+    if out is None:
+        out = torch.empty((B, C, F, H, W), dtype=torch.float16, device=rows.device)
+    if tuple(out.shape) != (B, C, F, H, W) or not out.is_contiguous():
+        raise VdxError("rows_to_ncfhw: bad out")
+    _lib.check(lib.vdx_rows_to_ncfhw_f16(_p(rows, "rows"), ld, _p(out, "out"), B, C, F, H, W, _stream()),
+               "vdx_rows_to_ncfhw_f16")
+    return out
+
+
+def silu(x, out=None):
+    lib = _lib.load()
+    if not x.is_contiguous():
+        raise VdxError("silu: x must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.vdx_silu_f16(_p(x, "x"), _p(out, "out"), x.numel(), _stream()), "vdx_silu_f16")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+_gn_ws: dict = {}
+
+
+def groupnorm(x, gamma, beta, *, groups, n_samples, rows_per_sample, eps, silu_act, x2=None, out=None):
+    """GroupNorm (+SiLU) over rows [n_samples*rows_per_sample][C]; x2 = second concat source."""
+    lib = _lib.load()
+    r, c1, ldx = _rows(x, "x")
+    c2, ldx2 = 0, 0
+    M = n_samples * rows_per_sample
+    if r < M:
+        raise VdxError(f"groupnorm: x has {r} rows, need {M}")
+    if x2 is not None:
+        r2, c2, ldx2 = _rows(x2, "x2")
+        if r2 < M:
+            raise VdxError(f"groupnorm: x2 has {r2} rows, need {M}")
+    Cc = c1 + c2
+    if gamma.numel() != Cc or beta.numel() != Cc:
+        raise VdxError(f"groupnorm: gamma/beta size {gamma.numel()} != C={Cc}")
+    if out is None:
+        out = torch.empty((M, Cc), dtype=torch.float16, device=x.device)
+    orow, ocol, ldy = _rows(out, "out")
+    if orow < M or ocol < Cc:
+        raise VdxError("groupnorm: out too small")
+    need = lib.vdx_groupnorm_workspace(n_samples, rows_per_sample, Cc, groups)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    _lib.check(lib.vdx_groupnorm_f16(_p(x, "x"), c1, ldx, _p(x2, "x2"), c2, ldx2, _p(gamma, "gamma"),
+                                     _p(beta, "beta"), float(eps), groups, n_samples, rows_per_sample,
+                                     int(bool(silu_act)), _p(out, "out"), ldy, ws.data_ptr(), _stream()),
+               "vdx_groupnorm_f16")
+    return out
+
+
+def layernorm(x, gamma, beta, *, M, eps=1e-5, out=None):
+    lib = _lib.load()
+    r, Cc, ldx = _rows(x, "x")
+    if r < M:
+        raise VdxError("layernorm: x too small")
+    if gamma.numel() != Cc or beta.numel() != Cc:
+        raise VdxError("layernorm: gamma/beta size")
+    if out is None:
+        out = torch.empty((M, Cc), dtype=torch.float16, device=x.device)
+    orow, ocol, ldy = _rows(out, "out")
+    if orow < M or ocol < Cc:
+        raise VdxError("layernorm: out too small")
+    _lib.check(lib.vdx_layernorm_f16(_p(x, "x"), ldx, _p(gamma, "gamma"), _p(beta, "beta"), float(eps), M, Cc,
+                                     _p(out, "out"), ldy, _stream()), "vdx_layernorm_f16")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, out=None):
+    """q rows [n_seq*sq][>=heads*64]; k rows [n_kv*skv_pad][>=heads*64]; vt [heads*64][>= n_kv*skv_pad]."""
+    lib = _lib.load()
+    qr, qc, ldq = _rows(q, "q")
+    kr, kc, ldk = _rows(k, "k")
+    vr, vc, ldvt = _rows(vt, "vt")
+    inner = heads * 64
+    n_kv = n_seq // seq_per_kv
+    if qr < n_seq * sq or qc < inner:
+        raise VdxError("flash_attn: q too small")
+    if kr < n_kv * skv_pad or kc < inner:
+        raise VdxError("flash_attn: k too small")
+    if vr < inner or vc < n_kv * skv_pad:
+        raise VdxError("flash_attn: vt too small")
+    if out is None:
+        out = torch.empty((n_seq * sq, inner), dtype=torch.float16, device=q.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < n_seq * sq or ocol < inner:
+        raise VdxError("flash_attn: out too small")
+    _lib.check(lib.vdx_flash_attn_f16(_p(q, "q"), ldq, _p(k, "k"), ldk, _p(vt, "vt"), ldvt, _p(out, "out"), ldo,
+                                      n_seq, sq, skv, skv_pad, heads, seq_per_kv, float(scale), _stream()),
+               "vdx_flash_attn_f16")
+    return out
+
+
+def temporal_attn(qkv, *, B, F, HW, heads, scale, out=None):
+    lib = _lib.load()
+    r, c, ld = _rows(qkv, "qkv")
+    inner = heads * 64
+    M = B * F * HW
+    if r < M or c < 3 * inner:
+        raise VdxError("temporal_attn: qkv too small")
+    if out is None:
+        out = torch.empty((M, inner), dtype=torch.float16, device=qkv.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < inner:
+        raise VdxError("temporal_attn: out too small")
+    _lib.check(lib.vdx_temporal_attn_f16(_p(qkv, "qkv"), ld, _p(out, "out"), ldo, B, F, HW, heads, float(scale),
+                                         _stream()), "vdx_temporal_attn_f16")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def cfg_input(lat, ctx, weight, out=None):
+    """fsdp_chunked_coherent.py:133-137: cat([lat]*2) (+ weight * ctx.repeat(F))."""
+    lib = _lib.load()
+    b, Cc, F, H, W = lat.shape
+    if b != 1 or not lat.is_contiguous():
+        raise VdxError("cfg_input: lat must be contiguous (1,C,F,H,W)")
+    if ctx is not None and (tuple(ctx.shape) != (1, Cc, 1, H, W) or not ctx.is_contiguous()):
+        raise VdxError("cfg_input: ctx must be contiguous (1,C,1,H,W)")
+    if out is None:
+        out = torch.empty((2, Cc, F, H, W), dtype=torch.float16, device=lat.device)
+    _lib.check(lib.vdx_cfg_input_f16(_p(lat, "lat"), _p(ctx, "ctx"), float(weight), _p(out, "out"), Cc, F, H * W,
+                                     _stream()), "vdx_cfg_input_f16")
+    return out
+
+
+def cfg_ddim_step(eps2, lat, guidance, coeffs, out=None):
+    """fsdp_chunked_coherent.py:141-142.  coeffs = (sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev))."""
+    lib = _lib.load()
+    if eps2.shape[0] != 2 or tuple(eps2.shape[1:]) != tuple(lat.shape[1:]) or lat.shape[0] != 1:
+        raise VdxError("cfg_ddim_step: eps2 must be (2,...) matching lat (1,...)")
+    if not (eps2.is_contiguous() and lat.is_contiguous()):
+        raise VdxError("cfg_ddim_step: tensors must be contiguous")
+    if out is None:
+        out = torch.empty_like(lat)
+    s1, sa, sp, s1p = (float(c) for c in coeffs)
+    _lib.check(lib.vdx_cfg_ddim_step_f16(_p(eps2, "eps2"), _p(lat, "lat"), _p(out, "out"), float(guidance),
+                                         s1, sa, sp, s1p, lat.numel(), _stream()), "vdx_cfg_ddim_step_f16")
+    return out
+
+
+def ddim_step(eps, lat, coeffs, out=None):
+    """`scheduler.step(eps, t, lat).prev_sample` (fsdp_chunked_coherent.py:142) without the CFG combine."""
+    lib = _lib.load()
+    if tuple(eps.shape) != tuple(lat.shape) or not (eps.is_contiguous() and lat.is_contiguous()):
+        raise VdxError("ddim_step: eps and lat must be contiguous and of equal shape")
+    if out is None:
+        out = torch.empty_like(lat)
+    s1, sa, sp, s1p = (float(c) for c in coeffs)
+    _lib.check(lib.vdx_ddim_step_f16(_p(eps, "eps"), _p(lat, "lat"), _p(out, "out"), s1, sa, sp, s1p,
+                                     lat.numel(), _stream()), "vdx_ddim_step_f16")
+    return out
+
+
+def blend_accumulate(full, weight, chunk, w, s, e):
+    lib = _lib.load()
+    _, Cc, T, H, W = full.shape
+    if tuple(chunk.shape) != (1, Cc, e - s, H, W) or not (chunk.is_contiguous() and full.is_contiguous()):
+        raise VdxError("blend_accumulate: chunk shape does not match range")
+    if weight.numel() != T or w.numel() != e - s:
+        raise VdxError("blend_accumulate: weight vectors")
+    _lib.check(lib.vdx_blend_accumulate_f16(_p(full, "full"), _p(weight, "weight", torch.float32),
+                                            _p(chunk, "chunk"), _p(w, "w", torch.float32), Cc, T, H * W, s, e,
+                                            _stream()), "vdx_blend_accumulate_f16")
+
+
+def blend_finalize(full, weight):
+    lib = _lib.load()
+    _, Cc, T, H, W = full.shape
+    out = torch.empty(full.shape, dtype=torch.float32, device=full.device)
+    _lib.check(lib.vdx_blend_finalize_f32(_p(full, "full"), _p(weight, "weight", torch.float32),
+                                          _p(out, "out", torch.float32), Cc, T, H * W, _stream()),
+               "vdx_blend_finalize_f32")
+    return out

@@ -1,0 +1,66 @@
+"""Weight re-layout from the diffusers state-dict shapes to the kernel layouts (include/vdx.h).
+
+Pure tensor reshapes/permutations done once at load time (on whatever device the weights are on).
+"""
+from __future__ import annotations
+
+import torch
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pad_rows(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    """Zero-pad the output-channel dimension (dim 0) to a multiple of `mult`."""
+    n = w.shape[0]
+    npad = round_up(n, mult)
+    if npad == n:
+        return w.contiguous()
+    out = w.new_zeros((npad,) + tuple(w.shape[1:]))
+    out[:n] = w
+    return out
+
+
+def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d weight [Cout][Cin][3][3] -> [Cout][9*Cin] with K = (ky*3+kx)*Cin + c."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+
+
+def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d 1x1 weight [Cout][Cin][1][1] (or Linear [Cout][Cin]) -> [Cout][Cin]."""
+    return w.reshape(w.shape[0], -1).contiguous()
+
+
+def pack_tconv3(w: torch.Tensor) -> torch.Tensor:
+    """Conv3d weight [Cout][Cin][3][1][1] -> [Cout][3*Cin] with K = kt*Cin + c."""
+    co, ci = w.shape[:2]
+    return w.reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).contiguous()
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU proj Linear(C, 8C): rows [0,4C) = value, [4C,8C) = gate.  Interleave in groups of 4
+    rows (value 4t..4t+3, gate 4t..4t+3) so that the GEMM epilogue finds value and gate of the
+    same output column in one lane (gemm.hip GEGLU epilogue)."""
+    n2, k = w.shape
+    half = n2 // 2
+    assert half % 4 == 0
+    wv = w[:half].reshape(half // 4, 1, 4, k)
+    wg = w[half:].reshape(half // 4, 1, 4, k)
+    wp = torch.cat([wv, wg], dim=1).reshape(n2, k).contiguous()
+    bv = b[:half].reshape(half // 4, 1, 4)
+    bg = b[half:].reshape(half // 4, 1, 4)
+    bp = torch.cat([bv, bg], dim=1).reshape(n2).contiguous()
+    return wp, bp
+
+
+def nchw_to_rows(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) -> rows [N*H*W][C] (test/helper use)."""
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
+
+
+def rows_to_nchw(r: torch.Tensor, n: int, h: int, w: int) -> torch.Tensor:
+    return r.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous()

@@ -1,0 +1,406 @@
+"""`UNet3DConditionModel` on hand-written gfx950 kernels, behind the diffusers call surface the
+reference uses (`Distribution/strategies/fsdp_chunked_coherent.py:140`):
+
+    noise = unet(x, t, encoder_hidden_states=emb).sample          # x (2,4,F,h,w) fp16
+
+and `unet.config.in_channels` (`:106,181,194`).  Architecture = diffusers UNet3DConditionModel for
+the Zeroscope/ModelScope config; weights are ingested from a diffusers
+state dict (same keys/shapes) and re-laid-out once for the kernels (packing.py).
+
+Physical layout: every activation is a channels-last fp16 row matrix [B*F*h*w][C]; the permutes
+diffusers performs between (BF,C,H,W), (B,C,F,H,W) and (BHW,F,C) are index arithmetic inside the
+kernels (conv gathers, 5-D GroupNorm statistics, temporal attention strides).
+
+There is NO CPU path: all arithmetic goes through libvdx_hip.so (ops.py raises otherwise).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from ._lib import VdxError
+
+
+@dataclass
+class UNet3DConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    attention_head_dim: int = 64
+    cross_attention_dim: int = 1024
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    transformer_in_heads: int = 8
+    down_block_types: Tuple[str, ...] = (
+        "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D")
+    up_block_types: Tuple[str, ...] = (
+        "UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D")
+
+    @staticmethod
+    def zeroscope() -> "UNet3DConfig":
+        return UNet3DConfig()
+
+
+TEXT_PAD = 128   # text tokens (77) padded to 2 key tiles; also keeps the K/V GEMM N % 64 == 0
+
+
+class UNet3DConditionModel(nn.Module):
+    """diffusers-compatible module; weights live in `self.W` (packed fp16 device tensors)."""
+
+    def __init__(self, cfg: Optional[UNet3DConfig] = None):
+        super().__init__()
+        self.cfg = cfg or UNet3DConfig.zeroscope()
+        c = self.cfg
+        if c.attention_head_dim != 64:
+            raise VdxError("attention kernels are built for head_dim 64")
+        for ch in c.block_out_channels:
+            if ch % 64 != 0:
+                raise VdxError("block_out_channels must be multiples of 64")
+        if c.cross_attention_dim % 64 != 0:
+            raise VdxError("cross_attention_dim must be a multiple of 64")
+        self.config = SimpleNamespace(in_channels=c.in_channels, out_channels=c.out_channels,
+                                      cross_attention_dim=c.cross_attention_dim,
+                                      block_out_channels=c.block_out_channels,
+                                      sample_size=None)
+        self.W: Dict[str, torch.Tensor] = {}
+        self._temb_slices: Dict[str, Tuple[int, int]] = {}
+        self._device = torch.device("cpu")
+        self.dtype = torch.float16
+
+    # ------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------
+    def _resnet_names(self) -> List[str]:
+        c = self.cfg
+        names = []
+        for i, t in enumerate(c.down_block_types):
+            names += [f"down_blocks.{i}.resnets.{j}" for j in range(c.layers_per_block)]
+        names += ["mid_block.resnets.0", "mid_block.resnets.1"]
+        for i, t in enumerate(c.up_block_types):
+            names += [f"up_blocks.{i}.resnets.{j}" for j in range(c.layers_per_block + 1)]
+        return names
+
+    @torch.no_grad()
+    def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor], device=None):
+        """Ingest a diffusers-format state dict (keys/shapes of SURVEY.md §8c (ii)) and pack it."""
+        dev = torch.device(device) if device is not None else self._device
+        W: Dict[str, torch.Tensor] = {}
+
+        def put(name, t):
+            W[name] = t.to(device=dev, dtype=torch.float16).contiguous()
+
+        used = set()
+
+        def get(k):
+            used.add(k)
+            return sd[k]
+
+        def lin(prefix, bias=True):
+            put(prefix + ".weight", packing.pack_conv1x1(get(prefix + ".weight")))
+            if bias:
+                put(prefix + ".bias", get(prefix + ".bias"))
+
+        def norm(prefix):
+            put(prefix + ".weight", get(prefix + ".weight"))
+            put(prefix + ".bias", get(prefix + ".bias"))
+
+        def attn_self(prefix, fuse_v):
+            q, k, v = (packing.pack_conv1x1(get(f"{prefix}.to_{n}.weight")) for n in "qkv")
+            if fuse_v:      # temporal attention: one [3*inner][inner] projection
+                put(prefix + ".to_qkv.weight", torch.cat([q, k, v], 0))
+            else:           # spatial self-attention: [q|k] fused, V issued as the swapped GEMM (-> V^T)
+                put(prefix + ".to_qk.weight", torch.cat([q, k], 0))
+                put(prefix + ".to_v.weight", v)
+            lin(prefix + ".to_out.0")
+
+        def attn_cross(prefix):
+            for n in "qkv":
+                put(f"{prefix}.to_{n}.weight", packing.pack_conv1x1(get(f"{prefix}.to_{n}.weight")))
+            lin(prefix + ".to_out.0")
+
+        def ff(prefix):
+            wp, bp = packing.pack_geglu(get(prefix + ".net.0.proj.weight"), get(prefix + ".net.0.proj.bias"))
+            put(prefix + ".net.0.proj.weight", wp)
+            put(prefix + ".net.0.proj.bias", bp)
+            lin(prefix + ".net.2")
+
+        def transformer(prefix, temporal):
+            norm(prefix + ".norm")
+            lin(prefix + ".proj_in")
+            b = prefix + ".transformer_blocks.0"
+            norm(b + ".norm1"); norm(b + ".norm2"); norm(b + ".norm3")
+            attn_self(b + ".attn1", fuse_v=temporal)
+            if temporal:
+                attn_self(b + ".attn2", fuse_v=True)
+            else:
+                attn_cross(b + ".attn2")
+            ff(b + ".ff")
+            lin(prefix + ".proj_out")
+
+        def resnet(prefix):
+            norm(prefix + ".norm1"); norm(prefix + ".norm2")
+            put(prefix + ".conv1.weight", packing.pack_conv3x3(get(prefix + ".conv1.weight")))
+            put(prefix + ".conv1.bias", get(prefix + ".conv1.bias"))
+            put(prefix + ".conv2.weight", packing.pack_conv3x3(get(prefix + ".conv2.weight")))
+            put(prefix + ".conv2.bias", get(prefix + ".conv2.bias"))
+            if prefix + ".conv_shortcut.weight" in sd:
+                lin(prefix + ".conv_shortcut")
+
+        def tconv(prefix):
+            for i, leaf in ((1, 2), (2, 3), (3, 3), (4, 3)):
+                norm(f"{prefix}.conv{i}.0")
+                put(f"{prefix}.conv{i}.weight", packing.pack_tconv3(get(f"{prefix}.conv{i}.{leaf}.weight")))
+                put(f"{prefix}.conv{i}.bias", get(f"{prefix}.conv{i}.{leaf}.bias"))
+
+        c = self.cfg
+        put("conv_in.weight", get("conv_in.weight").permute(0, 2, 3, 1))
+        put("conv_in.bias", get("conv_in.bias"))
+        lin("time_embedding.linear_1"); lin("time_embedding.linear_2")
+        transformer("transformer_in", True)
+        for i, t in enumerate(c.down_block_types):
+            p = f"down_blocks.{i}"
+            for j in range(c.layers_per_block):
+                resnet(f"{p}.resnets.{j}"); tconv(f"{p}.temp_convs.{j}")
+                if t.startswith("CrossAttn"):
+                    transformer(f"{p}.attentions.{j}", False)
+                    transformer(f"{p}.temp_attentions.{j}", True)
+            if i != len(c.block_out_channels) - 1:
+                put(f"{p}.downsamplers.0.conv.weight", packing.pack_conv3x3(get(f"{p}.downsamplers.0.conv.weight")))
+                put(f"{p}.downsamplers.0.conv.bias", get(f"{p}.downsamplers.0.conv.bias"))
+        for j in range(2):
+            resnet(f"mid_block.resnets.{j}"); tconv(f"mid_block.temp_convs.{j}")
+        transformer("mid_block.attentions.0", False)
+        transformer("mid_block.temp_attentions.0", True)
+        for i, t in enumerate(c.up_block_types):
+            p = f"up_blocks.{i}"
+            for j in range(c.layers_per_block + 1):
+                resnet(f"{p}.resnets.{j}"); tconv(f"{p}.temp_convs.{j}")
+                if t.startswith("CrossAttn"):
+                    transformer(f"{p}.attentions.{j}", False)
+                    transformer(f"{p}.temp_attentions.{j}", True)
+            if i != len(c.block_out_channels) - 1:
+                put(f"{p}.upsamplers.0.conv.weight", packing.pack_conv3x3(get(f"{p}.upsamplers.0.conv.weight")))
+                put(f"{p}.upsamplers.0.conv.bias", get(f"{p}.upsamplers.0.conv.bias"))
+        norm("conv_norm_out")
+        put("conv_out.weight", packing.pad_rows(packing.pack_conv3x3(get("conv_out.weight")), 64))
+        put("conv_out.bias", packing.pad_rows(get("conv_out.bias"), 64))
+
+        # all 22 time_emb_proj layers as ONE [sum(Cout)][temb] projection (one launch per forward)
+        ws, bs, off = [], [], 0
+        self._temb_slices = {}
+        for name in self._resnet_names():
+            w = packing.pack_conv1x1(get(name + ".time_emb_proj.weight"))
+            ws.append(w); bs.append(get(name + ".time_emb_proj.bias"))
+            self._temb_slices[name] = (off, w.shape[0])
+            off += w.shape[0]
+        put("time_emb_proj_all.weight", torch.cat(ws, 0))
+        put("time_emb_proj_all.bias", torch.cat(bs, 0))
+
+        missing = set(sd.keys()) - used
+        if missing:
+            raise VdxError(f"unexpected keys in state dict: {sorted(missing)[:5]} ... ({len(missing)})")
+        self.W = W
+        self._device = dev
+        return self
+
+    def _apply(self, fn, recurse=True):
+        # nn.Module.to()/cuda()/half(): move the packed store (floating tensors stay fp16)
+        out = super()._apply(fn, recurse)
+        if self.W:
+            probe = fn(torch.empty(0, dtype=torch.float16, device=self._device))
+            self.W = {k: v.to(probe.device) for k, v in self.W.items()}
+            self._device = probe.device
+        return out
+
+    def num_parameters(self) -> int:
+        return sum(v.numel() for v in self.W.values())
+
+    # ------------------------------------------------------------------------------------------
+    # building blocks (all on row matrices)
+    # ------------------------------------------------------------------------------------------
+    def _resnet(self, p, x, x2, temb_all, n_img, F, hh, ww):
+        W, g, eps = self.W, self.cfg.norm_num_groups, self.cfg.norm_eps
+        M, S = n_img * hh * ww, hh * ww
+        off, cout = self._temb_slices[p]
+        h = ops.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=n_img,
+                          rows_per_sample=S, eps=eps, silu_act=True, x2=x2)
+        geo = (n_img, hh, ww, hh, ww, 1, False)
+        h = ops.gemm(h, W[p + ".conv1.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
+                     bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, conv=geo)
+        h = ops.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups=g, n_samples=n_img,
+                          rows_per_sample=S, eps=eps, silu_act=True)
+        if p + ".conv_shortcut.weight" in W:
+            sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], M=M, a2=x2, bias=W[p + ".conv_shortcut.bias"])
+        else:
+            if x2 is not None:
+                raise VdxError(f"{p}: concat input needs a conv_shortcut")
+            sc = x
+        return ops.gemm(h, W[p + ".conv2.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv2.bias"],
+                        residual=sc, conv=geo)
+
+    def _temp_conv(self, p, x, B, F, S):
+        W, g = self.W, self.cfg.norm_num_groups
+        M = B * F * S
+        y = x
+        for i in (1, 2, 3, 4):
+            n = ops.groupnorm(y, W[f"{p}.conv{i}.0.weight"], W[f"{p}.conv{i}.0.bias"], groups=g, n_samples=B,
+                              rows_per_sample=F * S, eps=1e-5, silu_act=True)
+            y = ops.gemm(n, W[f"{p}.conv{i}.weight"], M=M, mode=ops.TCONV3, bias=W[f"{p}.conv{i}.bias"],
+                         tconv=(F, S), residual=x if i == 4 else None)
+        return y
+
+    def _ff(self, b, t, M):
+        W = self.W
+        ln = ops.layernorm(t, W[b + ".norm3.weight"], W[b + ".norm3.bias"], M=M)
+        gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=M, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
+        return ops.gemm(gg, W[b + ".ff.net.2.weight"], M=M, bias=W[b + ".ff.net.2.bias"], residual=t)
+
+    def _spatial_transformer(self, p, x, ehs_pad, n_img, F, hh, ww):
+        W, g = self.W, self.cfg.norm_num_groups
+        S, M = hh * ww, n_img * hh * ww
+        C = x.shape[1]
+        heads = C // 64
+        scale = 64 ** -0.5
+        if S % 8 != 0:
+            raise VdxError(f"spatial attention needs h*w % 8 == 0 at every level (got {hh}x{ww})")
+        b = p + ".transformer_blocks.0"
+        n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=n_img,
+                          rows_per_sample=S, eps=1e-6, silu_act=False)
+        t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
+        # --- self-attention
+        Mp = ops.round_up(M, 64)
+        ln = torch.empty((Mp, C), dtype=torch.float16, device=x.device)
+        if Mp != M:
+            ln[M:].zero_()
+        ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
+        qk = ops.gemm(ln, W[b + ".attn1.to_qk.weight"], M=M)
+        vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln, M=C)                       # V^T [C][Mp]
+        o = ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_img, sq=S, skv=S, skv_pad=S, heads=heads,
+                           seq_per_kv=1, scale=scale)
+        t = ops.gemm(o, W[b + ".attn1.to_out.0.weight"], M=M, bias=W[b + ".attn1.to_out.0.bias"], residual=t)
+        # --- cross-attention over the (padded) text tokens; all F frames of a sample share K/V
+        ln = ops.layernorm(t, W[b + ".norm2.weight"], W[b + ".norm2.bias"], M=M)
+        q = ops.gemm(ln, W[b + ".attn2.to_q.weight"], M=M)
+        nb = ehs_pad.shape[0] // TEXT_PAD
+        k = ops.gemm(ehs_pad, W[b + ".attn2.to_k.weight"], M=ehs_pad.shape[0])
+        vt = ops.gemm(W[b + ".attn2.to_v.weight"], ehs_pad, M=C)                  # [C][nb*TEXT_PAD]
+        o = ops.flash_attn(q, k, vt, n_seq=n_img, sq=S, skv=self._text_len, skv_pad=TEXT_PAD, heads=heads,
+                           seq_per_kv=n_img // nb, scale=scale)
+        t = ops.gemm(o, W[b + ".attn2.to_out.0.weight"], M=M, bias=W[b + ".attn2.to_out.0.bias"], residual=t)
+        t = self._ff(b, t, M)
+        return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
+
+    def _temporal_transformer(self, p, x, B, F, S, heads):
+        W, g = self.W, self.cfg.norm_num_groups
+        M = B * F * S
+        scale = 64 ** -0.5
+        b = p + ".transformer_blocks.0"
+        n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=B,
+                          rows_per_sample=F * S, eps=1e-6, silu_act=False)
+        t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
+        for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
+            ln = ops.layernorm(t, W[f"{b}.{nm}.weight"], W[f"{b}.{nm}.bias"], M=M)
+            qkv = ops.gemm(ln, W[f"{b}.{a}.to_qkv.weight"], M=M)
+            o = ops.temporal_attn(qkv, B=B, F=F, HW=S, heads=heads, scale=scale)
+            t = ops.gemm(o, W[f"{b}.{a}.to_out.0.weight"], M=M, bias=W[f"{b}.{a}.to_out.0.bias"], residual=t)
+        t = self._ff(b, t, M)
+        return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
+
+    # ------------------------------------------------------------------------------------------
+    def _time_embedding(self, timestep, B, device):
+        c0 = self.cfg.block_out_channels[0]
+        t = float(timestep)
+        half = c0 // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        a = torch.full((B, 1), t, dtype=torch.float32) * freqs[None]
+        return torch.cat([torch.cos(a), torch.sin(a)], dim=-1).to(torch.float16).to(device)
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, **_unused):
+        if not self.W:
+            raise VdxError("UNet3DConditionModel: no weights loaded (load_diffusers_state_dict)")
+        if not sample.is_cuda:
+            raise VdxError("UNet3DConditionModel.forward needs GPU tensors: the path has no CPU fallback")
+        c, W = self.cfg, self.W
+        dev = sample.device
+        if next(iter(W.values())).device != dev:
+            raise VdxError(f"weights are on {next(iter(W.values())).device}, input on {dev}")
+        B, Cin, F, H, Wd = sample.shape
+        if Cin != c.in_channels:
+            raise VdxError(f"sample has {Cin} channels, model expects {c.in_channels}")
+        nlev = len(c.block_out_channels)
+        if H % (2 ** (nlev - 1)) or Wd % (2 ** (nlev - 1)):
+            raise VdxError("latent height/width must be divisible by 8 (explicit upsample_size is not implemented)")
+        if F > 32:
+            raise VdxError("temporal attention kernel handles at most 32 frames per chunk")
+        sample = sample.to(torch.float16).contiguous()
+        ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16)
+        if ehs.shape[0] != B or ehs.shape[2] != c.cross_attention_dim or ehs.shape[1] > TEXT_PAD:
+            raise VdxError(f"encoder_hidden_states shape {tuple(ehs.shape)} does not fit (B={B}, dim={c.cross_attention_dim})")
+        self._text_len = ehs.shape[1]
+        ehs_pad = torch.zeros((B * TEXT_PAD, c.cross_attention_dim), dtype=torch.float16, device=dev)
+        ehs_pad.view(B, TEXT_PAD, -1)[:, :ehs.shape[1]] = ehs
+        n_img = B * F
+
+        # time embedding -> all time_emb_proj outputs [B][sum Cout]
+        temb = self._time_embedding(timestep, B, dev)
+        e = ops.gemm(temb, W["time_embedding.linear_1.weight"], M=B, bias=W["time_embedding.linear_1.bias"])
+        e = ops.gemm(ops.silu(e), W["time_embedding.linear_2.weight"], M=B, bias=W["time_embedding.linear_2.bias"])
+        temb_all = ops.gemm(ops.silu(e), W["time_emb_proj_all.weight"], M=B, bias=W["time_emb_proj_all.bias"])
+
+        hh, ww = H, Wd
+        x = ops.conv_in(sample, W["conv_in.weight"], W["conv_in.bias"])
+        x = self._temporal_transformer("transformer_in", x, B, F, hh * ww, c.transformer_in_heads)
+        skips = [(x, hh, ww)]
+        for i, t in enumerate(c.down_block_types):
+            p = f"down_blocks.{i}"
+            for j in range(c.layers_per_block):
+                x = self._resnet(f"{p}.resnets.{j}", x, None, temb_all, n_img, F, hh, ww)
+                x = self._temp_conv(f"{p}.temp_convs.{j}", x, B, F, hh * ww)
+                if t.startswith("CrossAttn"):
+                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs_pad, n_img, F, hh, ww)
+                    x = self._temporal_transformer(f"{p}.temp_attentions.{j}", x, B, F, hh * ww, x.shape[1] // 64)
+                skips.append((x, hh, ww))
+            if i != nlev - 1:
+                ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+                x = ops.gemm(x, W[f"{p}.downsamplers.0.conv.weight"], M=n_img * ho * wo, mode=ops.CONV3X3,
+                             bias=W[f"{p}.downsamplers.0.conv.bias"], conv=(n_img, hh, ww, ho, wo, 2, False))
+                hh, ww = ho, wo
+                skips.append((x, hh, ww))
+        # mid
+        x = self._resnet("mid_block.resnets.0", x, None, temb_all, n_img, F, hh, ww)
+        x = self._temp_conv("mid_block.temp_convs.0", x, B, F, hh * ww)
+        x = self._spatial_transformer("mid_block.attentions.0", x, ehs_pad, n_img, F, hh, ww)
+        x = self._temporal_transformer("mid_block.temp_attentions.0", x, B, F, hh * ww, x.shape[1] // 64)
+        x = self._resnet("mid_block.resnets.1", x, None, temb_all, n_img, F, hh, ww)
+        x = self._temp_conv("mid_block.temp_convs.1", x, B, F, hh * ww)
+        # up
+        for i, t in enumerate(c.up_block_types):
+            p = f"up_blocks.{i}"
+            for j in range(c.layers_per_block + 1):
+                skip, sh, sw = skips.pop()
+                if (sh, sw) != (hh, ww):
+                    raise VdxError("skip connection resolution mismatch")
+                x = self._resnet(f"{p}.resnets.{j}", x, skip, temb_all, n_img, F, hh, ww)
+                x = self._temp_conv(f"{p}.temp_convs.{j}", x, B, F, hh * ww)
+                if t.startswith("CrossAttn"):
+                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs_pad, n_img, F, hh, ww)
+                    x = self._temporal_transformer(f"{p}.temp_attentions.{j}", x, B, F, hh * ww, x.shape[1] // 64)
+            if i != nlev - 1:
+                x = ops.gemm(x, W[f"{p}.upsamplers.0.conv.weight"], M=n_img * 4 * hh * ww, mode=ops.CONV3X3,
+                             bias=W[f"{p}.upsamplers.0.conv.bias"], conv=(n_img, hh, ww, 2 * hh, 2 * ww, 1, True))
+                hh, ww = 2 * hh, 2 * ww
+        # out
+        n = ops.groupnorm(x, W["conv_norm_out.weight"], W["conv_norm_out.bias"], groups=c.norm_num_groups,
+                          n_samples=n_img, rows_per_sample=hh * ww, eps=c.norm_eps, silu_act=True)
+        y = ops.gemm(n, W["conv_out.weight"], M=n_img * hh * ww, mode=ops.CONV3X3, bias=W["conv_out.bias"],
+                     conv=(n_img, hh, ww, hh, ww, 1, False))
+        out = ops.rows_to_ncfhw(y, B, c.out_channels, F, hh, ww)
+        return SimpleNamespace(sample=out)

@@ -1,0 +1,144 @@
+/* vdx.h — C-ABI of libvdx_hip.so: the MI355X (gfx950) kernels behind the
+ * diffusers `UNet3DConditionModel` / `DDIMScheduler` call surface that the
+ * reference's `Distribution/strategies/fsdp_chunked_coherent.py` uses.
+ *
+ * The reference has no native code; every entry point below
+ * replaces a group of torch/diffusers operator calls reached from
+ *   fsdp_chunked_coherent.py:140   noise = self.unet(x, t, encoder_hidden_states=emb).sample
+ *   fsdp_chunked_coherent.py:133-137,141-142   ctx injection, CFG combine, scheduler.step
+ *   fsdp_chunked_coherent.py:204-217   linear-ramp overlap blend
+ * Each declaration cites the operator(s) it stands in for.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (the host side allocates through PyTorch-ROCm); no allocation, no sync inside;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, not waited for;
+ *   - return 0 on success, negative on error; `vdx_last_error()` gives the message
+ *     (thread-local);
+ *   - activations are fp16, channels-last: a (B,C,F,H,W) tensor of diffusers is held as the
+ *     row-major matrix [B*F*H*W rows][C] ("rows" = latent pixels of one frame);
+ *   - all contractions accumulate in fp32 on the matrix cores (v_mfma_f32_16x16x32_f16).
+ */
+#ifndef VDX_H
+#define VDX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vdx_stream_t;
+
+const char* vdx_last_error(void);
+int vdx_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM family:  out[M][N] = epilogue( A_gathered[M][K] * W[N][K]^T )
+ * Replaces torch.nn.Linear / Conv2d(3x3,1x1) / Conv3d((3,1,1)) as composed by diffusers
+ * ResnetBlock2D, TemporalConvLayer, Transformer2DModel, TransformerTemporalModel,
+ * Downsample2D, Upsample2D, all reached from
+ * fsdp_chunked_coherent.py:140.
+ * ---------------------------------------------------------------------------------------- */
+enum { VDX_GEMM_PLAIN = 0, VDX_GEMM_CONV3X3 = 1, VDX_GEMM_TCONV3 = 2 };
+enum { VDX_EPI_GEGLU = 1 };
+
+typedef struct vdx_gemm_args {
+    const void* a;        /* fp16 source 0, row stride lda (elements)                           */
+    const void* a2;       /* fp16 source 1 (channel concat after source 0) or NULL              */
+    const void* w;        /* fp16 [N][K], K contiguous; conv: K = tap*Ct + c, tap = ky*3+kx      */
+    const void* bias;     /* fp16 [N] or NULL                                                    */
+    const void* bias2;    /* fp16 [M / rows_per_bias2][N] or NULL (time-embedding projection)    */
+    const void* residual; /* fp16 [M][ldr] or NULL, added after bias                             */
+    void* out;            /* fp16 [M][ldo]   (GEGLU: [M][N/2])                                   */
+    int32_t M, N, K;      /* N % 64 == 0, K % 64 == 0                                            */
+    int32_t mode;         /* VDX_GEMM_*                                                          */
+    int32_t c1, c2;       /* channels of source 0 / 1; per-tap K = c1 + c2; both % 64 == 0       */
+    int32_t lda, lda2, ldo, ldr;
+    int32_t h_in, w_in;   /* conv3x3: source image size (rows of `a` = n*h_in*w_in)              */
+    int32_t h_out, w_out; /* conv3x3: output image size (M = n*h_out*w_out)                      */
+    int32_t stride;       /* conv3x3: 1 or 2 (pad 1)                                             */
+    int32_t upsample;     /* conv3x3: 1 = source is nearest-x2 upsampled on the fly              */
+    int32_t frames, hw;   /* tconv3: M = b*frames*hw, taps step `hw` rows, zero pad in time      */
+    int32_t rows_per_bias2, ldb2; /* bias2 row = m / rows_per_bias2, row stride ldb2 elements        */
+    int32_t epilogue;     /* VDX_EPI_* flags                                                     */
+} vdx_gemm_args;
+
+int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream);
+
+/* conv_in: Conv2d(4 -> C, 3x3, pad 1) reading the (B,Cin,F,H,W) fp16 latent directly
+ * (UNet3DConditionModel.conv_in after the permute/reshape).
+ * w: fp16 [Cout][3][3][Cin]; out: fp16 rows [B*F*H*W][Cout].                                   */
+int vdx_conv_in_f16(const void* x_ncfhw, const void* w, const void* bias, void* out,
+                    int B, int Cin, int F, int H, int W, int Cout, vdx_stream_t stream);
+
+/* channels-last rows [B*F*H*W][ld] (first C columns) -> (B,C,F,H,W) fp16 (UNet output permute) */
+int vdx_rows_to_ncfhw_f16(const void* rows, int ld, void* out, int B, int C, int F, int H, int W,
+                          vdx_stream_t stream);
+
+/* y = x * sigmoid(x), n elements (TimestepEmbedding act / ResnetBlock2D.nonlinearity(temb)) */
+int vdx_silu_f16(const void* x, void* y, size_t n, vdx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation (torch.nn.GroupNorm on 4-D and 5-D inputs, torch.nn.LayerNorm).
+ * GroupNorm over `rows_per_sample` rows x (C/G) channels per (sample, group):
+ *   4-D GN: rows_per_sample = H*W (sample = one frame); 5-D GN: rows_per_sample = F*H*W.
+ * Two sources (x | x2) cover the skip concatenation in up blocks.
+ * ---------------------------------------------------------------------------------------- */
+size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G);
+/* y[M][C] = act( (x - mean) * rstd * gamma + beta ), act = SiLU if silu != 0                   */
+int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
+                      const void* gamma, const void* beta, float eps, int G,
+                      int n_samples, int rows_per_sample, int silu,
+                      void* y, int ldy, void* workspace, vdx_stream_t stream);
+int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps,
+                      int M, int C, void* y, int ldy, vdx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention cores (diffusers `Attention` with plain softmax, scale = d^-0.5, head dim 64).
+ * ---------------------------------------------------------------------------------------- */
+/* Flash-style attention over contiguous sequences (spatial self-attention and text
+ * cross-attention of Transformer2DModel).
+ *   q  : fp16 rows [n_seq*sq][ldq], head h at columns h*64..h*64+63
+ *   k  : fp16 rows [n_kv*skv_pad][ldk]
+ *   vt : fp16 [heads*64][ldvt]  V transposed: vt[h*64+d][kvb*skv_pad + key]
+ *   kv batch of sequence s is s / seq_per_kv (cross-attn: all frames of a sample share text).
+ *   out: fp16 rows [n_seq*sq][ldo].                                                            */
+int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                       void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
+                       int seq_per_kv, float scale, vdx_stream_t stream);
+
+/* Temporal self-attention of TransformerTemporalModel: sequences run over the
+ * F frames of one latent pixel.  qkv: fp16 rows [B*F*HW][ldqkv] = [q | k | v] each heads*64
+ * wide, row = (b*F + f)*HW + p.  out rows likewise, [ldo] wide.  F <= 32.                      */
+int vdx_temporal_attn_f16(const void* qkv, int ldqkv, void* out, int ldo, int B, int F, int HW,
+                          int heads, float scale, vdx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Orchestration ops the reference owns (fsdp_chunked_coherent.py).
+ * ---------------------------------------------------------------------------------------- */
+/* :133-137  x = cat[lat,lat] (+ w * ctx.repeat(F));  lat (1,C,F,H,W), ctx (1,C,1,H,W) or NULL  */
+int vdx_cfg_input_f16(const void* lat, const void* ctx, float weight, void* x2, int C, int F,
+                      int HW, vdx_stream_t stream);
+/* :141-142  lat' = DDIM.step(u + gs*(c-u), t, lat)  with the four scheduler coefficients;
+ * eps2 (2,C,F,H,W) = [u; c].  Rounds to fp16 after every tensor op, like torch.              */
+int vdx_cfg_ddim_step_f16(const void* eps2, const void* lat, void* lat_out, float guidance,
+                          float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev,
+                          float sqrt_one_minus_aprev, size_t n, vdx_stream_t stream);
+/* :142 alone: lat' = DDIM.step(eps, t, lat) (no CFG combine) — what `scheduler.step` of the
+ * unchanged reference script binds to.                                                        */
+int vdx_ddim_step_f16(const void* eps, const void* lat, void* lat_out, float sqrt_one_minus_at,
+                      float sqrt_at, float sqrt_aprev, float sqrt_one_minus_aprev, size_t n,
+                      vdx_stream_t stream);
+/* :204-217 one chunk's contribution: full[s:e] += lat*w (fp16 accumulator), weight[s:e] += w;
+ * w = fp32 device vector of length e-s (the linear ramps, built by the host exactly as :207-213) */
+int vdx_blend_accumulate_f16(void* full, float* weight, const void* chunk, const float* w, int C,
+                             int T, int HW, int s, int e, vdx_stream_t stream);
+/* :217 lat = full / clamp(weight, 1e-6) -> fp32                                                */
+int vdx_blend_finalize_f32(const void* full, const float* weight, float* out, int C, int T,
+                           int HW, vdx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDX_H */

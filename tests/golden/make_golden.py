@@ -1,0 +1,83 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/), run in the build container.
+
+The reference's own Python cannot be imported here (no diffusers/cv2/pynvml) and
+holds no fixtures for this path, so the golden outputs come from the oracle restatement with
+seeded synthetic weights ("parity unpinned" at the diffusers boundary — see oracle/__init__.py).
+Inputs are regenerated from seeds by the tests; only expected outputs (+ the measured fp16 noise
+floor of the same computation on CPU) are stored.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.ddim_ref import DDIMSchedulerRef  # noqa: E402
+from oracle.pipeline_ref import run_video  # noqa: E402
+from oracle.unet3d_ref import UNet3DConditionModelRef, UNet3DConfig, synthetic_state_dict  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TINY = dict(ch=(64, 128, 128, 128), cross=128, in_heads=2)
+
+
+def tiny_inputs(F, H, W, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    sample = torch.randn(2, 4, F, H, W, generator=g).half()
+    ehs = torch.randn(2, 77, TINY["cross"], generator=g).half()
+    return sample, ehs
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+class FP32UNetOnHalfIO(torch.nn.Module):
+    """fp32 oracle UNet behind the reference's fp16 tensor interface."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+        self.config = m.config
+
+    def forward(self, x, t, encoder_hidden_states):
+        out = self.m(x.float(), t, encoder_hidden_states.float())
+        out.sample = out.sample.half()
+        return out
+
+
+def main():
+    torch.set_num_threads(8)
+    cfg = UNet3DConfig.tiny(**TINY)
+    sd = synthetic_state_dict(cfg, seed=1234)
+    sd16 = {k: v.half() for k, v in sd.items()}
+    m32 = UNet3DConditionModelRef(cfg).eval()
+    m32.load_state_dict({k: v.float() for k, v in sd16.items()})       # fp16-rounded weights, fp32 math
+    m16 = UNet3DConditionModelRef(cfg).eval().half()
+    m16.load_state_dict(sd16)
+    for tag, (F, H, W, t) in {"a": (4, 32, 32, 501), "b": (3, 32, 48, 981)}.items():
+        sample, ehs = tiny_inputs(F, H, W)
+        with torch.no_grad():
+            o32 = m32(sample.float(), torch.tensor(t), ehs.float()).sample
+            o16 = m16(sample, torch.tensor(t), ehs).sample
+        floor = rel_l2(o16.float(), o32)
+        print(f"unet_tiny_{tag}: out std {o32.std():.4f} max {o32.abs().max():.3f}  fp16-CPU floor rel-L2 {floor:.3e}")
+        np.savez_compressed(os.path.join(HERE, f"unet_tiny_{tag}.npz"), out=o32.numpy(), floor=np.float64(floor),
+                            shape=np.array([F, H, W, t]))
+    # end-to-end: planner -> shared noise -> ctx -> 3 CFG/DDIM steps per chunk -> ramp blend
+    T, H, W, steps = 10, 32, 32, 3
+    g = torch.Generator().manual_seed(1)
+    emb = torch.randn(2, 77, TINY["cross"], generator=g).half()
+    cond, uncond = emb[:1], emb[1:]
+    lat, (cs, ov, ranges) = run_video(FP32UNetOnHalfIO(m32), DDIMSchedulerRef(), T, 4, H, W, world=1, steps=steps,
+                                      uncond_emb=uncond, cond_emb=cond, chunk_size=6, overlap=2, mode="hybrid_ctx")
+    print("denoise_tiny:", cs, ov, ranges, "lat std", float(lat.std()))
+    np.savez_compressed(os.path.join(HERE, "denoise_tiny.npz"), lat=lat.numpy(), cs=cs, ov=ov,
+                        ranges=np.array(ranges), T=T, H=H, W=W, steps=steps)
+
+
+if __name__ == "__main__":
+    main()

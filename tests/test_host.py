@@ -1,0 +1,176 @@
+"""CPU suite (-m "not gpu"): host logic of the product against the oracle, and the C-ABI library
+(loads, exports every symbol include/vdx.h declares — no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import vdx  # noqa: F401
+from vdx import _lib, packing
+from vdx.planner import PlannerError, plan
+from vdx.scheduler import DDIMScheduler
+
+from oracle.ddim_ref import DDIMSchedulerRef
+from oracle.pipeline_ref import PlannerHang, my_ranges, plan_chunks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vdx.h")).read()
+    declared = set(re.findall(r"\b(vdx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/vdx.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().vdx_version() >= 1
+
+
+def test_gemm_args_struct_matches_header_field_order():
+    hdr = open(os.path.join(ROOT, "include", "vdx.h")).read()
+    body = re.search(r"typedef struct vdx_gemm_args \{(.*?)\} vdx_gemm_args;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(void\s*\*|int32_t)\s*", "", decl)
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert names == [f[0] for f in _lib.GemmArgs._fields_]
+
+
+@pytest.mark.parametrize("rule", ["coherent", "third"])
+def test_planner_matches_oracle_sweep(rule):
+    n = 0
+    for T in (8, 16, 24, 32, 48, 64, 96, 100):
+        for world in (1, 2, 3, 4, 6, 8):
+            for cs in (0, 6, 8, 16, 24):
+                for ov in (0, 2, 4):
+                    for no_chunk in (False, True):
+                        try:
+                            want = plan_chunks(T, world, cs, ov, no_chunk, rule)
+                        except PlannerHang:
+                            with pytest.raises(PlannerError):
+                                plan(T, world, cs, ov, no_chunk, rule)
+                            continue
+                        got = plan(T, world, cs, ov, no_chunk, rule)
+                        assert (got.chunk, got.overlap, list(got.ranges)) == want, (T, world, cs, ov, no_chunk)
+                        for r in range(world):
+                            assert got.for_rank(r) == my_ranges(want[2], world, r)
+                        assert len(got.ranges) % world == 0
+                        n += 1
+    assert n > 500
+
+
+def test_scheduler_tables_match_oracle():
+    a, b = DDIMScheduler(), DDIMSchedulerRef()
+    assert torch.equal(a.alphas_cumprod, b.alphas_cumprod)
+    for steps in (10, 50, 3):
+        a.set_timesteps(steps)
+        b.set_timesteps(steps)
+        assert a.timesteps.tolist() == b.timesteps.tolist() == a._host_timesteps
+        for t in a._host_timesteps:
+            assert a.coefficients(t) == tuple(float(c) for c in b.coefficients(t))
+    assert a.init_noise_sigma == 1.0
+    x = torch.zeros(3)
+    assert a.scale_model_input(x, 5) is x
+
+
+def test_scheduler_step_has_no_cpu_path():
+    s = DDIMScheduler()
+    s.set_timesteps(10)
+    with pytest.raises(_lib.VdxError):
+        s.step(torch.zeros(1, 4, 2, 8, 8, dtype=torch.float16), 901, torch.zeros(1, 4, 2, 8, 8, dtype=torch.float16))
+
+
+def test_packing_layouts():
+    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = packing.pack_conv3x3(w)
+    assert p.shape == (2, 27) and p[1, (1 * 3 + 2) * 3 + 1] == w[1, 1, 1, 2]
+    w3 = torch.arange(2 * 4 * 3, dtype=torch.float32).reshape(2, 4, 3, 1, 1)
+    p = packing.pack_tconv3(w3)
+    assert p.shape == (2, 12) and p[1, 2 * 4 + 3] == w3[1, 3, 2, 0, 0]
+    w = torch.arange(16 * 2, dtype=torch.float32).reshape(16, 2)
+    b = torch.arange(16, dtype=torch.float32)
+    wp, bp = packing.pack_geglu(w, b)
+    # rows: value 0-3, gate 0-3, value 4-7, gate 4-7
+    assert bp.tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
+    assert torch.equal(wp[:, 0] / 2, bp)
+    assert packing.pad_rows(torch.ones(4, 3)).shape == (64, 3)
+
+
+def test_unet_weight_ingest_covers_every_diffusers_key():
+    """Packing consumes every key of the diffusers-shaped table exactly once (meta tensors: no memory)."""
+    from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
+    from oracle.unet3d_ref import UNet3DConditionModelRef, UNet3DConfig as RefCfg
+    with torch.device("meta"):
+        ref = UNet3DConditionModelRef(RefCfg.zeroscope())
+    sd = dict(ref.state_dict())
+    m = UNet3DConditionModel(UNet3DConfig.zeroscope())
+    m.load_diffusers_state_dict(sd, device="meta")
+    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60        # + conv_out rows padded 4 -> 64
+    assert m.config.in_channels == 4
+    sd["bogus.weight"] = torch.empty(1, device="meta")
+    with pytest.raises(_lib.VdxError):
+        UNet3DConditionModel(UNet3DConfig.zeroscope()).load_diffusers_state_dict(sd, device="meta")
+
+
+GLOO_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import vdx
+from vdx.pipeline import gather_chunks
+from vdx.planner import plan
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cp = plan(24, world, 0, 4)
+C, H, W = 4, 3, 5
+mine = []
+for (s, e) in cp.for_rank(rank):
+    t = torch.arange(s, e, dtype=torch.float16).view(1, 1, e - s, 1, 1).expand(1, C, e - s, H, W).contiguous()
+    mine.append(t * (rank + 1))
+out = gather_chunks(mine, cp, rank, world)
+# reference order: rank-major (for lst in gathered: for s,e,latc in lst)
+want = [r for rr in range(world) for r in cp.for_rank(rr)]
+assert [(s, e) for s, e, _ in out] == want, (out, want)
+for i, (s, e, t) in enumerate(out):
+    owner = [rr for rr in range(world) if (s, e) in cp.for_rank(rr)][0]
+    ref = torch.arange(s, e, dtype=torch.float16).view(1, 1, e - s, 1, 1).expand(1, C, e - s, H, W) * (owner + 1)
+    assert t.shape == (1, C, e - s, H, W) and torch.equal(t, ref)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_chunk_gather_two_ranks_gloo(tmp_path):
+    script = tmp_path / "gather.py"
+    script.write_text(GLOO_SCRIPT.format(root=ROOT))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
+
+
+def test_state_dict_spec_matches_oracle_module_tree():
+    from vdx.unet3d import UNet3DConfig
+    from vdx.weights import state_dict_spec, synthetic_state_dict
+    from oracle.unet3d_ref import UNet3DConditionModelRef, UNet3DConfig as RefCfg
+    for ref_cfg, cfg in ((RefCfg.zeroscope(), UNet3DConfig.zeroscope()),
+                         (RefCfg.tiny(), UNet3DConfig(block_out_channels=(64, 128, 128, 128),
+                                                      cross_attention_dim=128, transformer_in_heads=2))):
+        with torch.device("meta"):
+            ref = UNet3DConditionModelRef(ref_cfg)
+        want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        assert state_dict_spec(cfg) == want
+    sd = synthetic_state_dict(cfg, seed=3)
+    assert set(sd) == set(want) and all(v.dtype == torch.float16 for v in sd.values())
+    assert abs(float(sd["conv_norm_out.weight"].float().mean()) - 1.0) < 0.05
+    assert abs(float(sd["mid_block.temp_convs.0.conv2.0.weight"].float().mean()) - 1.0) < 0.05

@@ -1,0 +1,332 @@
+"""-m gpu: every HIP kernel of libvdx_hip.so against a plain PyTorch fp32 CPU reference of the
+same operator (the primitives diffusers composes), called through the C-ABI via vdx.ops.
+Orchestration kernels (ctx injection, CFG+DDIM, blend) are compared BIT-EXACT with the oracle
+(oracle/pipeline_ref.py, oracle/ddim_ref.py) which restates fsdp_chunked_coherent.py on CPU fp16.
+Tolerance for fp16-output contractions: |err| <= 3e-3 * max|ref| + 3e-3 * |ref|  (one fp16
+rounding of an fp32-accumulated result is 4.9e-4 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import vdx  # noqa: F401
+    from vdx import ops, packing
+    return ops, packing
+
+
+def h(x):  # fp16-rounded fp32 CPU tensor
+    return x.half().float()
+
+
+def close(out, ref, tol=3e-3):
+    out = out.float().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all()
+    scale = ref.abs().max().item() + 1e-6
+    err = (out - ref).abs()
+    bound = tol * scale + tol * ref.abs()
+    bad = (err > bound)
+    assert not bad.any(), f"max err {err.max().item():.4g} (scale {scale:.4g}), {int(bad.sum())} / {bad.numel()} bad"
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(2, 64, 64), (100, 128, 320), (300, 320, 128), (257, 640, 64), (128, 192, 1024)])
+@pytest.mark.parametrize("flags", ["none", "bias", "bias+res", "bias2", "all"])
+def test_gemm_plain(gpu, M, N, K, flags):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = h(torch.randn(N, generator=g)) if "bias" in flags or flags == "all" else None
+    res = h(torch.randn(M, N, generator=g)) if "res" in flags or flags == "all" else None
+    rpb = 37
+    b2 = h(torch.randn((M + rpb - 1) // rpb, N, generator=g)) if flags in ("bias2", "all") else None
+    ref = a @ w.t()
+    if bias is not None:
+        ref = ref + bias
+    if b2 is not None:
+        ref = ref + b2.repeat_interleave(rpb, 0)[:M]
+    if res is not None:
+        ref = ref + res
+    d = lambda t: None if t is None else t.half().to(gpu)
+    out = ops.gemm(d(a), d(w), M=M, bias=d(bias), bias2=d(b2), rows_per_bias2=rpb if b2 is not None else 0,
+                   residual=d(res))
+    close(out, ref)
+
+
+def test_gemm_two_sources_and_strided_views(gpu):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, c1, c2, N = 200, 128, 64, 128
+    a1, a2 = h(torch.randn(M, c1, generator=g)), h(torch.randn(M, c2, generator=g))
+    w = h(torch.randn(N, c1 + c2, generator=g) / 14)
+    ref = torch.cat([a1, a2], 1) @ w.t()
+    # sources are column slices of wider buffers (lda > c)
+    buf1 = torch.zeros(M, 256, dtype=torch.float16, device=gpu)
+    buf1[:, 64:64 + c1] = a1.half().to(gpu)
+    buf2 = torch.zeros(M + 3, 64, dtype=torch.float16, device=gpu)
+    buf2[:M] = a2.half().to(gpu)
+    outbuf = torch.zeros(M, 512, dtype=torch.float16, device=gpu)
+    ops.gemm(buf1[:, 64:64 + c1], w.half().to(gpu), M=M, a2=buf2, out=outbuf[:, 128:128 + N])
+    close(outbuf[:, 128:128 + N], ref)
+    assert outbuf[:, :128].abs().max() == 0 and outbuf[:, 256:].abs().max() == 0
+
+
+def test_gemm_swapped_gives_transposed_product(gpu):
+    """V^T = Wv . X^T : the same kernel with weights as `a` and activations as `w`."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(6)
+    tokens, C = 192, 128
+    x = h(torch.randn(tokens, C, generator=g))
+    wv = h(torch.randn(C, C, generator=g) / 11)
+    vt = ops.gemm(wv.half().to(gpu), x.half().to(gpu), M=C)
+    close(vt, (x @ wv.t()).t().contiguous())
+
+
+@pytest.mark.parametrize("M,C", [(70, 64), (260, 320)])
+def test_gemm_geglu(gpu, M, C):
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(M + C)
+    x = h(torch.randn(M, C, generator=g))
+    w = h(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    b = h(torch.randn(8 * C, generator=g) * 0.1)
+    a_, g_ = (x @ w.t() + b).chunk(2, dim=-1)
+    ref = a_ * F.gelu(g_)
+    wp, bp = packing.pack_geglu(w.half(), b.half())
+    out = ops.gemm(x.half().to(gpu), wp.to(gpu), M=M, bias=bp.to(gpu), geglu=True)
+    assert out.shape == (M, 4 * C)
+    close(out, ref)
+
+
+@pytest.mark.parametrize("cin,cout,n,hh,ww,stride,ups", [
+    (64, 64, 3, 6, 10, 1, False), (128, 320, 2, 9, 7, 1, False), (64, 128, 2, 8, 12, 2, False),
+    (64, 64, 2, 7, 9, 2, False), (64, 128, 2, 5, 6, 1, True)])
+def test_conv3x3(gpu, cin, cout, n, hh, ww, stride, ups):
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(cin + cout + hh)
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = h(torch.randn(cout, generator=g) * 0.1)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref4 = F.conv2d(xin, w, b, stride=stride, padding=1)
+    ho, wo = ref4.shape[2:]
+    temb = h(torch.randn(n, cout, generator=g))
+    res = h(torch.randn(n * ho * wo, cout, generator=g))
+    ref = packing.nchw_to_rows(ref4 + temb[:, :, None, None]) + res
+    out = ops.gemm(packing.nchw_to_rows(x).half().to(gpu), packing.pack_conv3x3(w).half().to(gpu),
+                   M=n * ho * wo, mode=ops.CONV3X3, bias=b.half().to(gpu),
+                   bias2=temb.half().to(gpu), rows_per_bias2=ho * wo, residual=res.half().to(gpu),
+                   conv=(n, hh, ww, ho, wo, stride, ups))
+    close(out, ref)
+
+
+@pytest.mark.parametrize("B,Fr,HW,C,Co", [(2, 5, 12, 64, 64), (1, 24, 9, 128, 128), (2, 1, 10, 64, 128)])
+def test_tconv3(gpu, B, Fr, HW, C, Co):
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(Fr + C)
+    x5 = h(torch.randn(B, C, Fr, HW, 1, generator=g))
+    w = h(torch.randn(Co, C, 3, 1, 1, generator=g) / math.sqrt(3 * C))
+    b = h(torch.randn(Co, generator=g) * 0.1)
+    ref5 = F.conv3d(x5, w, b, padding=(1, 0, 0))                       # (B,Co,F,HW,1)
+    rows = x5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, C)
+    ref = ref5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, Co)
+    res = h(torch.randn(B * Fr * HW, Co, generator=g))
+    out = ops.gemm(rows.half().to(gpu), packing.pack_tconv3(w).half().to(gpu), M=B * Fr * HW, mode=ops.TCONV3,
+                   bias=b.half().to(gpu), residual=res.half().to(gpu), tconv=(Fr, HW))
+    close(out, ref + res)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns,rps,c1,c2,G,silu", [
+    (6, 35, 64, 0, 32, True), (3, 300, 320, 0, 32, True), (2, 130, 64, 128, 32, True),
+    (4, 16, 128, 0, 32, False), (2, 513, 1280, 640, 32, True)])
+def test_groupnorm(gpu, ns, rps, c1, c2, G, silu):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(ns + rps + c1)
+    C = c1 + c2
+    x = h(torch.randn(ns * rps, C, generator=g) * 2 + torch.randn(1, C, generator=g))
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.3 * torch.randn(C, generator=g))
+    eps = 1e-5
+    x3 = x.reshape(ns, rps, C).permute(0, 2, 1)                      # (N, C, L)
+    ref = F.group_norm(x3, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(ns * rps, C)
+    xd = x.half().to(gpu)
+    x1 = xd[:, :c1].contiguous()
+    x2 = xd[:, c1:].contiguous() if c2 else None
+    out = ops.groupnorm(x1, gamma.half().to(gpu), beta.half().to(gpu), groups=G, n_samples=ns,
+                        rows_per_sample=rps, eps=eps, silu_act=silu, x2=x2)
+    close(out, ref, tol=4e-3)
+
+
+@pytest.mark.parametrize("M,C", [(37, 64), (100, 320), (9, 1280), (5, 512)])
+def test_layernorm(gpu, M, C):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(M + C)
+    x = h(torch.randn(M, C, generator=g) * 3 + 1)
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.3 * torch.randn(C, generator=g))
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    out = ops.layernorm(x.half().to(gpu), gamma.half().to(gpu), beta.half().to(gpu), M=M)
+    close(out, ref, tol=4e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, heads):
+    n, s, _ = q.shape
+    qh = q.view(n, s, heads, 64).transpose(1, 2)
+    kh = k.view(n, -1, heads, 64).transpose(1, 2)
+    vh = v.view(n, -1, heads, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(n * s, heads * 64)
+
+
+@pytest.mark.parametrize("n_seq,s,heads", [(3, 144, 2), (2, 64, 1), (2, 200, 3), (1, 576, 2)])
+def test_flash_self_attention(gpu, n_seq, s, heads):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(n_seq + s)
+    inner = heads * 64
+    M = n_seq * s
+    Mp = ops.round_up(M, 64)
+    qkv = h(torch.randn(M, 3 * inner, generator=g))
+    q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    ref = _attn_ref(q.reshape(n_seq, s, inner), k.reshape(n_seq, s, inner), v.reshape(n_seq, s, inner), heads)
+    qkv_d = qkv.half().to(gpu)
+    vt = torch.zeros(inner, Mp, dtype=torch.float16, device=gpu)
+    vt[:, :M] = v.t().half().to(gpu)
+    out = ops.flash_attn(qkv_d[:, :inner], qkv_d[:, inner:2 * inner], vt, n_seq=n_seq, sq=s, skv=s, skv_pad=s,
+                         heads=heads, seq_per_kv=1, scale=0.125)
+    close(out, ref, tol=4e-3)
+
+
+def test_flash_attention_large_scores_online_rescale(gpu):
+    """Forces the running max to jump at a late tile (one key row spiked against every query)."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(11)
+    s, heads = 320, 1
+    q = h(torch.randn(s, 64, generator=g))
+    k = h(torch.randn(s, 64, generator=g))
+    v = h(torch.randn(s, 64, generator=g))
+    k[300] = h(q.mean(0) * 40 + 3)
+    ref = _attn_ref(q[None], k[None], v[None], heads)
+    vt = v.t().contiguous().half().to(gpu)
+    out = ops.flash_attn(q.half().to(gpu), k.half().to(gpu), vt, n_seq=1, sq=s, skv=s, skv_pad=s, heads=heads,
+                         seq_per_kv=1, scale=0.125)
+    close(out, ref, tol=4e-3)
+
+
+@pytest.mark.parametrize("B,Fr,s,heads,skv", [(2, 3, 144, 2, 77), (1, 4, 64, 1, 77), (2, 2, 100, 2, 5)])
+def test_flash_cross_attention(gpu, B, Fr, s, heads, skv):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(B + Fr + s)
+    inner = heads * 64
+    skv_pad = 128
+    q = h(torch.randn(B * Fr, s, inner, generator=g))
+    k = h(torch.randn(B, skv, inner, generator=g))
+    v = h(torch.randn(B, skv, inner, generator=g))
+    ref = _attn_ref(q, k.repeat_interleave(Fr, 0), v.repeat_interleave(Fr, 0), heads)
+    kd = torch.zeros(B * skv_pad, inner, dtype=torch.float16, device=gpu)
+    vt = torch.zeros(inner, B * skv_pad, dtype=torch.float16, device=gpu)
+    for b in range(B):
+        kd[b * skv_pad:b * skv_pad + skv] = k[b].half().to(gpu)
+        vt[:, b * skv_pad:b * skv_pad + skv] = v[b].t().half().to(gpu)
+    out = ops.flash_attn(q.reshape(-1, inner).half().to(gpu), kd, vt, n_seq=B * Fr, sq=s, skv=skv, skv_pad=skv_pad,
+                         heads=heads, seq_per_kv=Fr, scale=0.125)
+    close(out, ref, tol=4e-3)
+
+
+@pytest.mark.parametrize("B,Fr,HW,heads", [(2, 5, 7, 2), (1, 24, 12, 5), (2, 32, 3, 1), (1, 1, 9, 2), (2, 16, 130, 8)])
+def test_temporal_attention(gpu, B, Fr, HW, heads):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(B + Fr + HW)
+    inner = heads * 64
+    qkv = h(torch.randn(B * Fr * HW, 3 * inner, generator=g))
+    # sequences over frames for every (b, pixel)
+    t = qkv.reshape(B, Fr, HW, 3 * inner).permute(0, 2, 1, 3).reshape(B * HW, Fr, 3 * inner)
+    o = _attn_ref(t[..., :inner], t[..., inner:2 * inner], t[..., 2 * inner:], heads)
+    ref = o.reshape(B, HW, Fr, inner).permute(0, 2, 1, 3).reshape(B * Fr * HW, inner)
+    out = ops.temporal_attn(qkv.half().to(gpu), B=B, F=Fr, HW=HW, heads=heads, scale=0.125)
+    close(out, ref, tol=4e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_conv_in_and_output_permute(gpu):
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, Cin, Fr, H, W, Cout = 2, 4, 3, 6, 10, 64
+    x = h(torch.randn(B, Cin, Fr, H, W, generator=g))
+    w = h(torch.randn(Cout, Cin, 3, 3, generator=g) / 6)
+    b = h(torch.randn(Cout, generator=g) * 0.1)
+    x4 = x.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cin, H, W)
+    ref = packing.nchw_to_rows(F.conv2d(x4, w, b, padding=1))
+    out = ops.conv_in(x.half().to(gpu), w.permute(0, 2, 3, 1).contiguous().half().to(gpu), b.half().to(gpu))
+    close(out, ref)
+    # rows -> (B,C,F,H,W) takes the first C columns
+    back = ops.rows_to_ncfhw(out, B, 4, Fr, H, W)
+    want = out[:, :4].float().cpu().reshape(B, Fr, H, W, 4).permute(0, 4, 1, 2, 3)
+    assert torch.equal(back.float().cpu(), want)
+
+
+def test_silu(gpu):
+    ops, _ = _ops()
+    x = h(torch.randn(2, 1280))
+    close(ops.silu(x.half().to(gpu)), F.silu(x))
+
+
+# ---- orchestration kernels: bit-exact against the oracle -----------------------------------------
+def test_cfg_input_bit_exact(gpu):
+    ops, _ = _ops()
+    from oracle.pipeline_ref import base_noise, global_context
+    T, C, H, W = 6, 4, 8, 8
+    lat = base_noise(T, C, H, W)
+    ctx = global_context(T, C, H, W)
+    want = torch.cat([lat] * 2) + 0.35 * ctx.repeat(1, 1, T, 1, 1)     # fsdp_chunked_coherent.py:133-137
+    got = ops.cfg_input(lat.to(gpu), ctx.to(gpu), 0.35)
+    assert torch.equal(got.cpu(), want)
+    got = ops.cfg_input(lat.to(gpu), None, 0.35)
+    assert torch.equal(got.cpu(), torch.cat([lat] * 2))
+
+
+@pytest.mark.parametrize("steps", [10, 50])
+def test_cfg_ddim_step_bit_exact(gpu, steps):
+    ops, _ = _ops()
+    from oracle.ddim_ref import DDIMSchedulerRef
+    s = DDIMSchedulerRef()
+    s.set_timesteps(steps)
+    g = torch.Generator().manual_seed(steps)
+    lat = torch.randn(1, 4, 5, 8, 8, generator=g).half()
+    for t in s.timesteps[[0, 1, steps // 2, steps - 1]]:
+        noise = torch.randn(2, 4, 5, 8, 8, generator=g).half()
+        u, c = noise.chunk(2)
+        want = s.step(u + 7.5 * (c - u), t, lat).prev_sample          # :141-142
+        got = ops.cfg_ddim_step(noise.to(gpu), lat.to(gpu), 7.5, s.coefficients(int(t)))
+        assert want.dtype == torch.float16
+        assert torch.equal(got.cpu(), want), f"t={int(t)}: {(got.cpu().float() - want.float()).abs().max()}"
+        lat = want
+
+
+def test_blend_bit_exact(gpu):
+    ops, _ = _ops()
+    from oracle.pipeline_ref import plan_chunks, ramp_blend
+    T, C, H, W = 24, 4, 6, 6
+    cs, ov, ranges = plan_chunks(T, 2, 0, 4)
+    g = torch.Generator().manual_seed(9)
+    chunks = [(s, e, torch.randn(1, C, e - s, H, W, generator=g).half()) for s, e in ranges]
+    like = torch.zeros(1, C, T, H, W, dtype=torch.float16)
+    want = ramp_blend(chunks, T, ov, like)
+    full = torch.zeros(1, C, T, H, W, dtype=torch.float16, device=gpu)
+    weight = torch.zeros(T, dtype=torch.float32, device=gpu)
+    ramp = torch.linspace(0, 1, ov)
+    for s, e, lat in chunks:
+        w = torch.ones(e - s)
+        k = min(ov, e - s)
+        w[:k] = ramp[:k]
+        w[-k:] = torch.flip(ramp[:k], [0])
+        ops.blend_accumulate(full, weight, lat.to(gpu), w.to(gpu), s, e)
+    got = ops.blend_finalize(full, weight)
+    assert torch.equal(got.cpu(), want)
