@@ -2,8 +2,19 @@
 // orchestration ops the reference owns: ctx injection (fsdp_chunked_coherent.py:133-137),
 // CFG combine + DDIM step (:141-142), linear-ramp blend (:204-217).
 // The orchestration kernels round to fp16 after every tensor op, in the order torch evaluates
-// the reference's expressions, so they are bit-exact against the CPU oracle.
+// the reference's expressions ON A GPU (the reference's tensors live on `cuda`): a 0-d fp32
+// coefficient stays fp32 on either side of `*`, and `/ cpu_scalar` is `* (1/scalar)`.  ctx
+// injection and blend are bit-exact against the CPU oracle; for the DDIM step torch-CPU differs
+// from torch-GPU in exactly those two rules (oracle/ddim_ref.py `step_gpu_rules` restates them).
 #include "vdx_common.h"
+
+// fp32 -> fp16 as its own rounding step: the empty asm keeps hipcc from fusing the preceding fp32
+// op and this conversion into v_fma_mixlo_f16 (one rounding), so results match torch's
+// "compute in fp32, then cast" for fp16 tensors bit for bit.
+__device__ __forceinline__ f16 rn16(float x) {
+    asm volatile("" : "+v"(x));
+    return (f16)x;
+}
 
 // ---- conv_in: Conv2d(Cin -> Cout, 3x3, pad 1) straight from the (B,Cin,F,H,W) latent ---------
 __global__ void conv_in_kernel(const f16* x, const f16* w, const f16* bias, f16* out, int B, int Cin,
@@ -102,8 +113,8 @@ __global__ void cfg_input_kernel(const f16* lat, const f16* ctx, float weight, f
         if (ctx) {
             const int p = (int)(i % HW);
             const int c = (int)(i / ((size_t)HW * F));
-            const f16 t = (f16)__fmul_rn((float)ctx[(size_t)c * HW + p], weight);  // fp16(cw * ctx)
-            v = (f16)__fadd_rn((float)v, (float)t);                                 // fp16(x + t)
+            const f16 t = rn16(__fmul_rn((float)ctx[(size_t)c * HW + p], weight));  // fp16(cw * ctx)
+            v = rn16(__fadd_rn((float)v, (float)t));                                 // fp16(x + t)
         }
         x2[i] = v;
         x2[n + i] = v;
@@ -126,15 +137,15 @@ __global__ void cfg_ddim_kernel(const f16* eps2, const f16* lat, f16* out, float
                                 float sp, float s1p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float u = (float)eps2[i], c = (float)eps2[n + i], x = (float)lat[i];
-        const f16 t1 = (f16)__fsub_rn(c, u);                 // c - u
-        const f16 t2 = (f16)__fmul_rn(gs, (float)t1);        // gs * (c - u)
-        const f16 g = (f16)__fadd_rn(u, (float)t2);          // u + gs*(c-u)
-        const f16 a1 = (f16)__fmul_rn(s1, (float)g);         // sqrt(1-a_t) * eps
-        const f16 a2 = (f16)__fsub_rn(x, (float)a1);         // sample - ...
-        const f16 x0 = (f16)__fdiv_rn((float)a2, sa);        // / sqrt(a_t)
-        const f16 d = (f16)__fmul_rn(s1p, (float)g);         // sqrt(1-a_prev) * eps
-        const f16 b1 = (f16)__fmul_rn(sp, (float)x0);        // sqrt(a_prev) * x0
-        out[i] = (f16)__fadd_rn((float)b1, (float)d);
+        const f16 t1 = rn16(__fsub_rn(c, u));                 // c - u
+        const f16 t2 = rn16(__fmul_rn(gs, (float)t1));        // gs * (c - u)
+        const f16 g = rn16(__fadd_rn(u, (float)t2));          // u + gs*(c-u)
+        const f16 a1 = rn16(__fmul_rn(s1, (float)g));         // sqrt(1-a_t) * eps
+        const f16 a2 = rn16(__fsub_rn(x, (float)a1));         // sample - ...
+        const f16 x0 = rn16(__fmul_rn((float)a2, sa));        // * (1/sqrt(a_t)): torch-GPU divides by a CPU scalar this way
+        const f16 d = rn16(__fmul_rn(s1p, (float)g));         // sqrt(1-a_prev) * eps
+        const f16 b1 = rn16(__fmul_rn(sp, (float)x0));        // sqrt(a_prev) * x0
+        out[i] = rn16(__fadd_rn((float)b1, (float)d));
     }
 }
 extern "C" int vdx_cfg_ddim_step_f16(const void* eps2, const void* lat, void* lat_out, float guidance,
@@ -143,7 +154,7 @@ extern "C" int vdx_cfg_ddim_step_f16(const void* eps2, const void* lat, void* la
     VDX_CHECK(eps2 && lat && lat_out && n > 0, "cfg_ddim_step: bad arguments");
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)eps2,
-                       (const f16*)lat, (f16*)lat_out, guidance, sqrt_one_minus_at, sqrt_at, sqrt_aprev,
+                       (const f16*)lat, (f16*)lat_out, guidance, sqrt_one_minus_at, 1.0f / sqrt_at, sqrt_aprev,
                        sqrt_one_minus_aprev, n);
     return vdx_launch_status("vdx_cfg_ddim_step_f16");
 }
@@ -154,12 +165,12 @@ __global__ void ddim_kernel(const f16* eps, const f16* lat, f16* out, float s1, 
                             size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float g = (float)eps[i], x = (float)lat[i];
-        const f16 a1 = (f16)__fmul_rn(s1, g);
-        const f16 a2 = (f16)__fsub_rn(x, (float)a1);
-        const f16 x0 = (f16)__fdiv_rn((float)a2, sa);
-        const f16 d = (f16)__fmul_rn(s1p, g);
-        const f16 b1 = (f16)__fmul_rn(sp, (float)x0);
-        out[i] = (f16)__fadd_rn((float)b1, (float)d);
+        const f16 a1 = rn16(__fmul_rn(s1, g));
+        const f16 a2 = rn16(__fsub_rn(x, (float)a1));
+        const f16 x0 = rn16(__fmul_rn((float)a2, sa));
+        const f16 d = rn16(__fmul_rn(s1p, g));
+        const f16 b1 = rn16(__fmul_rn(sp, (float)x0));
+        out[i] = rn16(__fadd_rn((float)b1, (float)d));
     }
 }
 extern "C" int vdx_ddim_step_f16(const void* eps, const void* lat, void* lat_out, float sqrt_one_minus_at,
@@ -168,7 +179,7 @@ extern "C" int vdx_ddim_step_f16(const void* eps, const void* lat, void* lat_out
     VDX_CHECK(eps && lat && lat_out && n > 0, "ddim_step: bad arguments");
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(ddim_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)eps,
-                       (const f16*)lat, (f16*)lat_out, sqrt_one_minus_at, sqrt_at, sqrt_aprev,
+                       (const f16*)lat, (f16*)lat_out, sqrt_one_minus_at, 1.0f / sqrt_at, sqrt_aprev,
                        sqrt_one_minus_aprev, n);
     return vdx_launch_status("vdx_ddim_step_f16");
 }
@@ -185,8 +196,9 @@ __global__ void blend_acc_kernel(f16* full, float* weight, const f16* chunk, con
         const int f = (int)((i / HW) % len);
         const int c = (int)(i / ((size_t)HW * len));
         const size_t di = ((size_t)c * T + s + f) * HW + p;
-        const float prod = __fmul_rn((float)chunk[i], w[f]);
-        full[di] = (f16)__fadd_rn((float)full[di], prod);
+        float prod = __fmul_rn((float)chunk[i], w[f]);
+        asm volatile("" : "+v"(prod));   // keep the fp32 product a separate rounding (no fma_mix)
+        full[di] = rn16(__fadd_rn((float)full[di], prod));
     }
 }
 extern "C" int vdx_blend_accumulate_f16(void* full, float* weight, const void* chunk, const float* w, int C, int T,

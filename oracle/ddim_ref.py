@@ -55,3 +55,18 @@ class DDIMSchedulerRef:
         x0 = (sample - s1 * eps) / sa
         prev = sp * x0 + s1p * eps
         return SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
+
+    def step_gpu_rules(self, eps, t, sample):
+        """The same expression evaluated with torch's GPU type rules for fp16 tensors (what the
+        reference executes: its tensors are on `cuda`).  torch-CPU differs in two places, measured
+        in this container: (1) a 0-d fp32 tensor as the LEFT operand of `*` is first cast to fp16 on
+        CPU, kept fp32 (opmath) on GPU; (2) `tensor / cpu_scalar` is a true division on CPU and
+        `tensor * (1/scalar)` on GPU (`div_true_kernel_cuda`).  Every tensor op still rounds its
+        result to fp16."""
+        s1, sa, sp, s1p = (c.float() for c in self.coefficients(int(t)))
+        r = lambda x: x.half()  # noqa: E731
+        e, x = eps.float(), sample.float()
+        a2 = r(x - r(s1 * e).float())
+        x0 = r(a2.float() * (torch.tensor(1.0) / sa))
+        prev = r(r(sp * x0.float()).float() + r(s1p * e).float())
+        return SimpleNamespace(prev_sample=prev, pred_original_sample=x0)

