@@ -16,57 +16,41 @@ __device__ __forceinline__ f16 rn16(float x) {
     return (f16)x;
 }
 
-// ---- conv_in: Conv2d(Cin -> Cout, 3x3, pad 1) straight from the (B,Cin,F,H,W) latent ---------
-__global__ void conv_in_kernel(const f16* x, const f16* w, const f16* bias, f16* out, int B, int Cin,
-                               int F, int H, int W, int Cout) {
-    extern __shared__ f16 ws[];  // [Cout][9*Cin]
-    const int K = 9 * Cin;
-    for (int i = threadIdx.x; i < Cout * K; i += blockDim.x) ws[i] = w[i];
-    __syncthreads();
-    const int nvec = Cout >> 3;
+// ---- conv_in gather: (B,Cin,F,H,W) latent -> im2col rows [B*F*H*W][Kpad], K = (ky*3+kx)*Cin + ci
+// (zero padded to Kpad, a multiple of 64) so conv_in runs on the MFMA GEMM like every other conv.
+__global__ void im2col_in_kernel(const f16* x, f16* out, int B, int Cin, int F, int H, int W, int Kpad) {
+    const int nvec = Kpad >> 3;
     const long long total = (long long)B * F * H * W * nvec;
-    const int HW = H * W;
+    const int HW = H * W, K = 9 * Cin;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int cv = (int)(idx % nvec);
+        const int kv = (int)(idx % nvec);
         const long long pix = idx / nvec;
         const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
         const int f = (int)((pix / HW) % F), b = (int)(pix / ((long long)HW * F));
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bias ? (float)bias[cv * 8 + j] : 0.f;
-        for (int ky = 0; ky < 3; ++ky) {
-            const int y = yy + ky - 1;
-            if ((unsigned)y >= (unsigned)H) continue;
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xq = xx + kx - 1;
-                if ((unsigned)xq >= (unsigned)W) continue;
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float v = (float)x[(((size_t)b * Cin + ci) * F + f) * HW + y * W + xq];
-                    const int k = (ky * 3 + kx) * Cin + ci;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += v * (float)ws[(cv * 8 + j) * K + k];
-                }
-            }
-        }
         f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)acc[j];
-        *(f16x8*)(out + (size_t)pix * Cout + cv * 8) = o;
+        for (int j = 0; j < 8; ++j) {
+            const int k = kv * 8 + j;
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int y = yy + tap / 3 - 1, xq = xx + tap % 3 - 1;
+            const bool ok = k < K && (unsigned)y < (unsigned)H && (unsigned)xq < (unsigned)W;
+            o[j] = ok ? x[(((size_t)b * Cin + ci) * F + f) * HW + y * W + xq] : (f16)0.f;
+        }
+        *(f16x8*)(out + (size_t)pix * Kpad + kv * 8) = o;
     }
 }
 
-extern "C" int vdx_conv_in_f16(const void* x, const void* w, const void* bias, void* out, int B, int Cin,
-                               int F, int H, int W, int Cout, vdx_stream_t stream) {
-    VDX_CHECK(x && w && out, "conv_in: null pointer");
-    VDX_CHECK(B > 0 && Cin > 0 && F > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv_in: bad shape");
-    const size_t lds = (size_t)Cout * 9 * Cin * sizeof(f16);
-    VDX_CHECK(lds <= 64 * 1024, "conv_in: weights (%zu B) exceed the LDS budget", lds);
-    const long long total = (long long)B * F * H * W * (Cout / 8);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv_in_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const f16*)x,
-                       (const f16*)w, (const f16*)bias, (f16*)out, B, Cin, F, H, W, Cout);
-    return vdx_launch_status("vdx_conv_in_f16");
+extern "C" int vdx_im2col_in_f16(const void* x, void* out, int B, int Cin, int F, int H, int W, int Kpad,
+                                 vdx_stream_t stream) {
+    VDX_CHECK(x && out, "im2col_in: null pointer");
+    VDX_CHECK(B > 0 && Cin > 0 && F > 0 && H > 0 && W > 0, "im2col_in: bad shape");
+    VDX_CHECK(Kpad % 64 == 0 && Kpad >= 9 * Cin, "im2col_in: Kpad=%d must be a multiple of 64 >= 9*Cin", Kpad);
+    const long long total = (long long)B * F * H * W * (Kpad / 8);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(im2col_in_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)out,
+                       B, Cin, F, H, W, Kpad);
+    return vdx_launch_status("vdx_im2col_in_f16");
 }
 
 // ---- rows [B*F*HW][ld] -> (B,C,F,H,W) -------------------------------------------------------

@@ -9,17 +9,16 @@
 // Data layout: activations channels-last rows [pixels][C] so a K-slice of 64 channels of one
 // row is one 128-byte line; weights [N][K] with K = tap*C + c.
 //
-// Tiling: BM x BN x 64 block tile, waves own 64x64 (16 accumulators of v_mfma_f32_16x16x32_f16),
-// LDS rows of 128 B XOR-swizzled by (row & 7) so every ds_read_b128 / ds_write_b128 is
-// conflict-free, LDS double-buffered with ONE barrier per K-tile, next tile's global loads
-// issued before the MFMA block and written to LDS after it (register staging: the gather can
-// zero-fill padding taps, which an LDS-DMA load cannot).
-// The MFMA is issued with the weight fragment as the A operand, so a lane ends up holding
+// Tiling: BM x BN x 64 block tile, waves own 64x64 (16 accumulators of v_mfma_f32_16x16x32_f16).
+// Staging is LDS-DMA (global_load_lds_dwordx4): every lane supplies its own 16-byte SOURCE
+// address — which is what makes the conv gathers, the zero padding (source = a 128-byte zero
+// page), the concat and the N/M tails free — while the LDS image stays lane-linear (1 KiB = 8 rows
+// of 128 B per wave-instruction).  The XOR swizzle that makes every ds_read_b128 conflict-free is
+// therefore applied to the source chunk index and to the read address, never to the destination.
+// LDS is double-buffered with ONE barrier per K-tile: tile k+1 streams in while tile k feeds the
+// MFMAs.  The MFMA is issued with the weight fragment as the A operand, so a lane ends up holding
 // 8 consecutive output channels of one row -> 16-byte epilogue stores.
 #include "vdx_common.h"
-
-// 128 zero bytes: padding taps / rows past M read from here, so every gather load is unconditional.
-
 
 struct GemmP {
     const f16 *a, *a2, *w, *bias, *bias2, *res;
@@ -31,6 +30,9 @@ struct GemmP {
     int ntn;
 };
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int NT = WM * WN * 64;
@@ -38,28 +40,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int ACH = BM * 8 / NT, BCH = BN * 8 / NT;
     constexpr int STAGE = (BM + BN) * 128;
-    static_assert(TN % 2 == 0 && ACH >= 1 && BCH >= 1, "tile shape");
+    static_assert(TN % 2 == 0 && ACH >= 1 && BCH >= 1 && NT % 8 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
 
-    // ---- per-thread gather descriptors (fixed across K tiles) ------------------------------
-    const int cchunk = tid & 7;           // 16-byte chunk inside the 128-byte K-slice
+    // ---- per-thread staging descriptors (fixed across K tiles) ------------------------------
+    // DMA instruction i of this wave fills LDS rows (i*NT + wave*64)/8 .. +7; lane l lands at row
+    // +(l>>3), 16-byte slot l&7.  Slot s of physical row r must hold data chunk s ^ (r & 7).
+    const int prow = tid >> 3;                         // physical row of chunk 0 (chunk i: + i*NT/8)
+    const int csw = ((tid & 7) ^ (prow & 7)) * 8;      // element offset of the data chunk this lane fetches
     size_t a_off[ACH];                    // MODE 0: row offset in source 0;  MODE 1/2: see below
     size_t a_off2[ACH];                   // MODE 0: row offset in source 1
     int a_y[ACH], a_x[ACH];               // MODE 1: top-left tap coords;  MODE 2: a_y = frame idx
     bool a_ok[ACH];
-    int a_lds[ACH];
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-        const int r = (i * NT + tid) >> 3;
-        const int m = m0 + r;
+        const int m = m0 + prow + i * (NT / 8);
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
-        a_lds[i] = r * 128 + ((cchunk ^ (r & 7)) << 4);
         if (MODE == 0) {
             a_off[i] = (size_t)mm * p.lda;
             a_off2[i] = (size_t)mm * p.lda2;
@@ -79,32 +82,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
             a_off2[i] = 0;
         }
     }
-    size_t b_off[BCH];
-    int b_lds[BCH];
+    const f16* zp = (const f16*)g_zero_page;
+    const f16* b_src[BCH];                // weight row base (+ data chunk) or the zero page (N tail)
+    int b_step[BCH];                      // elements to advance per K tile (0 for the zero page)
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-        const int r = (i * NT + tid) >> 3;
-        // LDS row permutation inside each 32-row group: global row 8q+4b+j -> LDS row 16b+4q+j,
+        // Physical LDS row pr holds weight row 8q+4b+j where pr = 16b+4q+j inside each 32-row group,
         // so that after the MFMA a lane owns 8 consecutive output columns.
-        const int pr = (r & ~31) | (((r >> 2) & 1) << 4) | (((r >> 3) & 3) << 2) | (r & 3);
-        b_lds[i] = BM * 128 + pr * 128 + ((cchunk ^ (pr & 7)) << 4);
-        b_off[i] = (size_t)(n0 + r) * p.K + cchunk * 8;
+        const int pr = prow + i * (NT / 8);
+        const int r = (pr & ~31) | (((pr >> 2) & 3) << 3) | (((pr >> 4) & 1) << 2) | (pr & 3);
+        const bool ok = n0 + r < p.N;
+        b_src[i] = ok ? p.w + (size_t)(n0 + r) * p.K + csw : zp;
+        b_step[i] = ok ? 64 : 0;
     }
 
-    // ---- K-tile walker ---------------------------------------------------------------------
+    // ---- K-tile walker: issue the LDS-DMA of one tile ---------------------------------------
     const int ct = p.c1 + p.c2;           // channels per tap
-    int tap = 0, kc = 0;                  // state of the NEXT tile to be loaded
-    u32x4 ra[ACH], rb[BCH];
-    const f16* zp = (const f16*)g_zero_page;
-    auto gload = [&](int kt) {
+    int tap = 0, kc = 0;                  // state of the NEXT tile to be issued
+    auto issue = [&](int buf) {
+        char* sa = smem + buf * STAGE + wave * 1024;
+        char* sb = sa + BM * 128;
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) rb[i] = *(const u32x4*)(p.w + b_off[i] + (size_t)kt * 64);
+        for (int i = 0; i < BCH; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)b_src[i], (lptr_t)(sb + i * NT * 16), 16, 0, 0);
+            b_src[i] += b_step[i];
+        }
         if (MODE == 0) {
             const bool first = kc < p.c1;
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
                 const f16* src = first ? p.a + a_off[i] + kc : p.a2 + a_off2[i] + (kc - p.c1);
-                ra[i] = *(const u32x4*)(a_ok[i] ? src + cchunk * 8 : zp);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_ok[i] ? src + csw : zp), (lptr_t)(sa + i * NT * 16), 16, 0, 0);
             }
         } else if (MODE == 1) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -115,27 +123,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                 const bool ok = a_ok[i] && (unsigned)y < (unsigned)hlim && (unsigned)x < (unsigned)wlim;
                 y >>= p.ups;
                 x >>= p.ups;
-                const f16* src = p.a + (a_off[i] + (size_t)(y * p.w_in + x)) * p.lda + kc + cchunk * 8;
-                ra[i] = *(const u32x4*)(ok ? src : zp);
+                const f16* src = p.a + (a_off[i] + (size_t)(y * p.w_in + x)) * p.lda + kc + csw;
+                __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * NT * 16), 16, 0, 0);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
                 const int f = a_y[i] + tap - 1;
                 const bool ok = a_ok[i] && (unsigned)f < (unsigned)p.frames;
-                const f16* src = p.a + (a_off[i] + (size_t)((tap - 1) * p.hw)) * p.lda + kc + cchunk * 8;
-                ra[i] = *(const u32x4*)(ok ? src : zp);
+                const f16* src = p.a + (a_off[i] + (size_t)((tap - 1) * p.hw)) * p.lda + kc + csw;
+                __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * NT * 16), 16, 0, 0);
             }
         }
         kc += 64;
         if (kc == ct) { kc = 0; ++tap; }
-    };
-    auto lstore = [&](int buf) {
-        char* s = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) *(u32x4*)(s + a_lds[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) *(u32x4*)(s + b_lds[i]) = rb[i];
     };
 
     f32x4 acc[TM][TN];
@@ -146,36 +147,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
 
     const int nk = p.K >> 6;
     const int frow = lane & 15, fq = lane >> 4;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    issue(0);
+    __syncthreads();                      // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) issue(cur ^ 1);  // buffer cur^1 was last read before the previous barrier
         const char* As = smem + cur * STAGE;
         const char* Bs = As + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 af[TM], bf[TN];
+            f16x8 af[TM];
             const int c = ks * 4 + fq;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm * WTM + i * 16 + frow;
                 af[i] = *(const f16x8*)(As + row * 128 + ((c ^ (row & 7)) << 4));
             }
+            // weight fragments in groups of <= 5 (bounds live registers on the 160-wide wave tile)
+            constexpr int NG = TN > 5 ? 2 : 1, GS = TN / NG;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * WTN + j * 16 + frow;
-                bf[j] = *(const f16x8*)(Bs + row * 128 + ((c ^ (row & 7)) << 4));
+            for (int g = 0; g < NG; ++g) {
+                f16x8 bf[GS];
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    const int row = wn * WTN + (g * GS + j) * 16 + frow;
+                    bf[j] = *(const f16x8*)(Bs + row * 128 + ((c ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < GS; ++j)
+                        acc[i][g * GS + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][g * GS + j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
+        __syncthreads();                  // next tile landed (vmcnt(0)) and this one is fully read
     }
 
     // ---- epilogue: lane holds rows m = ..+frow, 8 consecutive columns per accumulator pair --
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int a = 0; a < TN / 2; ++a) {
             const int n = n0 + wn * WTN + a * 32 + fq * 8;
+            if (n >= p.N) continue;
             float v[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -235,7 +242,7 @@ static int launch(const GemmP& p, hipStream_t st) {
         attr_set = true;
     }
     GemmP q = p;
-    q.ntn = p.N / BN;
+    q.ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(kern, dim3(ntm * q.ntn), dim3(WM * WN * 64), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16");
@@ -243,7 +250,13 @@ static int launch(const GemmP& p, hipStream_t st) {
 
 template <int MODE, bool GEGLU>
 static int pick_tile(const GemmP& p, hipStream_t st) {
-    if (p.N % 128 == 0) return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
+    // 128x128 tiles everywhere (N tails such as 320 = 2.5 tiles are masked: still faster than the
+    // 256x64 shape, profiles/r01_first_path_kernel_stats.csv); 256x64 only for a 64-wide output.
+    // Channel widths of this UNet are multiples of 320: a 256x320 tile (8 waves, 64x160 per wave,
+    // 144 KB of LDS, one block per CU) halves LDS/L2 bytes per MFMA against 128x128.
+    if (p.N % 320 == 0 && (long long)((p.M + 255) / 256) * (p.N / 320) >= 192)
+        return launch<256, 320, 4, 2, MODE, GEGLU>(p, st);
+    if (p.N > 64) return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
     return launch<256, 64, 4, 1, MODE, GEGLU>(p, st);
 }
 

@@ -112,35 +112,37 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     ev0.record()
     _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
     ev1.record()
-    PROFILE.append((gemm_kernel_name(N, mode, geglu), 2.0 * M * N * K, ev0, ev1))
+    PROFILE.append((gemm_kernel_name(M, N, mode, geglu), 2.0 * M * N * K, ev0, ev1))
     return out
 
 
 PROFILE = None   # set to a list by bench.py to collect (kernel name, algorithmic FLOPs, start, end)
 
 
-def gemm_kernel_name(N: int, mode: int, geglu: bool) -> str:
+def gemm_kernel_name(M: int, N: int, mode: int, geglu: bool) -> str:
     """Name of the instantiation gemm.hip's pick_tile() launches (as rocprofv3 prints it)."""
-    tile = "128, 128, 2, 2" if N % 128 == 0 else "256, 64, 4, 1"
+    if N % 320 == 0 and ((M + 255) // 256) * (N // 320) >= 192:
+        tile = "256, 320, 4, 2"
+    else:
+        tile = "128, 128, 2, 2" if N > 64 else "256, 64, 4, 1"
     return f"gemm_kernel<{tile}, {0 if geglu else mode}, {'true' if geglu else 'false'}>"
 
 
 def conv_in(x, w, bias, out=None):
-    """x (B,Cin,F,H,W) fp16 -> rows [B*F*H*W][Cout]; w [Cout][3][3][Cin]."""
+    """x (B,Cin,F,H,W) fp16 -> rows [B*F*H*W][Cout]; w [Cout][Kpad] = pack_conv3x3 zero-padded in K
+    to a multiple of 64.  im2col gather (HBM-light: Cin = 4) + the MFMA GEMM."""
     lib = _lib.load()
     B, Cin, F, H, W = x.shape
     if not x.is_contiguous():
         raise VdxError("conv_in: x must be contiguous (B,C,F,H,W)")
-    Cout = w.shape[0]
-    if w.numel() != Cout * 9 * Cin or not w.is_contiguous():
-        raise VdxError("conv_in: w must be contiguous [Cout][3][3][Cin]")
-    if out is None:
-        out = torch.empty((B * F * H * W, Cout), dtype=torch.float16, device=x.device)
-    if out.shape[0] < B * F * H * W or out.shape[1] != Cout or not out.is_contiguous():
-        raise VdxError("conv_in: bad out")
-    _lib.check(lib.vdx_conv_in_f16(_p(x, "x"), _p(w, "w"), _p(bias, "bias"), _p(out, "out"),
-                                   B, Cin, F, H, W, Cout, _stream()), "vdx_conv_in_f16")
-    return out
+    Cout, Kpad = w.shape
+    if Kpad % 64 != 0 or Kpad < 9 * Cin or not w.is_contiguous():
+        raise VdxError("conv_in: w must be contiguous [Cout][Kpad], Kpad a multiple of 64 >= 9*Cin")
+    M = B * F * H * W
+    cols = torch.empty((M, Kpad), dtype=torch.float16, device=x.device)
+    _lib.check(lib.vdx_im2col_in_f16(_p(x, "x"), _p(cols, "cols"), B, Cin, F, H, W, Kpad, _stream()),
+               "vdx_im2col_in_f16")
+    return gemm(cols, w, M=M, bias=bias, out=out)
 
 
 def rows_to_ncfhw(rows, B, C, F, H, W, out=None):

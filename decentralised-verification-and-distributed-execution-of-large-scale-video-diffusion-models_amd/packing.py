@@ -29,6 +29,16 @@ def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
 
 
+def pack_conv_in(w: torch.Tensor) -> torch.Tensor:
+    """conv_in weight [Cout][Cin][3][3] -> [Cout][Kpad]: K = (ky*3+kx)*Cin + c zero-padded to a
+    multiple of 64 (matches the im2col rows of vdx_im2col_in_f16)."""
+    p = pack_conv3x3(w)
+    k = p.shape[1]
+    out = p.new_zeros((p.shape[0], round_up(k, 64)))
+    out[:, :k] = p
+    return out
+
+
 def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
     """Conv2d 1x1 weight [Cout][Cin][1][1] (or Linear [Cout][Cin]) -> [Cout][Cin]."""
     return w.reshape(w.shape[0], -1).contiguous()

@@ -160,7 +160,7 @@ class UNet3DConditionModel(nn.Module):
                 put(f"{prefix}.conv{i}.bias", get(f"{prefix}.conv{i}.{leaf}.bias"))
 
         c = self.cfg
-        put("conv_in.weight", get("conv_in.weight").permute(0, 2, 3, 1))
+        put("conv_in.weight", packing.pack_conv_in(get("conv_in.weight")))
         put("conv_in.bias", get("conv_in.bias"))
         lin("time_embedding.linear_1"); lin("time_embedding.linear_2")
         transformer("transformer_in", True)

@@ -66,11 +66,11 @@ typedef struct vdx_gemm_args {
 
 int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream);
 
-/* conv_in: Conv2d(4 -> C, 3x3, pad 1) reading the (B,Cin,F,H,W) fp16 latent directly
- * (UNet3DConditionModel.conv_in after the permute/reshape).
- * w: fp16 [Cout][3][3][Cin]; out: fp16 rows [B*F*H*W][Cout].                                   */
-int vdx_conv_in_f16(const void* x_ncfhw, const void* w, const void* bias, void* out,
-                    int B, int Cin, int F, int H, int W, int Cout, vdx_stream_t stream);
+/* conv_in gather: (B,Cin,F,H,W) fp16 latent -> im2col rows [B*F*H*W][Kpad], K = (ky*3+kx)*Cin + ci,
+ * zero padded to Kpad (multiple of 64); conv_in = this + vdx_gemm_f16 with w [Cout][Kpad]
+ * (UNet3DConditionModel.conv_in after the permute/reshape).                         */
+int vdx_im2col_in_f16(const void* x_ncfhw, void* out_rows, int B, int Cin, int F, int H, int W,
+                      int Kpad, vdx_stream_t stream);
 
 /* channels-last rows [B*F*H*W][ld] (first C columns) -> (B,C,F,H,W) fp16 (UNet output permute) */
 int vdx_rows_to_ncfhw_f16(const void* rows, int ld, void* out, int B, int C, int F, int H, int W,

@@ -114,7 +114,8 @@ def test_unet_weight_ingest_covers_every_diffusers_key():
     sd = dict(ref.state_dict())
     m = UNet3DConditionModel(UNet3DConfig.zeroscope())
     m.load_diffusers_state_dict(sd, device="meta")
-    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60        # + conv_out rows padded 4 -> 64
+    # + conv_out rows padded 4 -> 64, conv_in K padded 36 -> 64
+    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28
     assert m.config.in_channels == 4
     sd["bogus.weight"] = torch.empty(1, device="meta")
     with pytest.raises(_lib.VdxError):

@@ -59,6 +59,46 @@ def test_gemm_plain(gpu, M, N, K, flags):
     close(out, ref)
 
 
+def test_gemm_big_tile_all_modes(gpu):
+    """Shapes large enough (>= 192 tiles of 256x320) to take the 8-wave 256x320 kernel in every mode,
+    with M tails (M % 256 != 0)."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(77)
+    d = lambda t: t.half().to(gpu)
+    # plain, two sources, bias + residual: M = 12300 rows, N = 1280
+    M, c1, c2, N = 12300, 64, 64, 1280
+    a1, a2 = h(torch.randn(M, c1, generator=g)), h(torch.randn(M, c2, generator=g))
+    w = h(torch.randn(N, c1 + c2, generator=g) / 11)
+    b, res = h(torch.randn(N, generator=g)), h(torch.randn(M, N, generator=g))
+    assert ops.gemm_kernel_name(M, N, 0, False).startswith("gemm_kernel<256, 320")
+    close(ops.gemm(d(a1), d(w), M=M, a2=d(a2), bias=d(b), residual=d(res)), torch.cat([a1, a2], 1) @ w.t() + b + res)
+    # GEGLU: C = 320 -> N = 2560
+    M, C = 6200, 320
+    x = h(torch.randn(M, C, generator=g))
+    w = h(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    bb = h(torch.randn(8 * C, generator=g) * 0.1)
+    a_, g_ = (x @ w.t() + bb).chunk(2, dim=-1)
+    wp, bp = packing.pack_geglu(w.half(), bb.half())
+    assert ops.gemm_kernel_name(M, 8 * C, 0, True).startswith("gemm_kernel<256, 320")
+    close(ops.gemm(d(x), wp.to(gpu), M=M, bias=bp.to(gpu), geglu=True), a_ * F.gelu(g_))
+    # conv3x3 with temb bias: 3 images of 63x65, 64 -> 1280
+    n, hh, ww, cin, cout = 3, 63, 65, 64, 1280
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / 24)
+    temb = h(torch.randn(n, cout, generator=g))
+    ref = packing.nchw_to_rows(F.conv2d(x, w, None, padding=1) + temb[:, :, None, None])
+    assert ops.gemm_kernel_name(n * hh * ww, cout, 1, False).startswith("gemm_kernel<256, 320")
+    close(ops.gemm(d(packing.nchw_to_rows(x)), d(packing.pack_conv3x3(w)), M=n * hh * ww, mode=ops.CONV3X3,
+                   bias2=d(temb), rows_per_bias2=hh * ww, conv=(n, hh, ww, hh, ww, 1, False)), ref)
+    # temporal conv: B=2, F=6, HW=1030, 64 -> 1280
+    B, Fr, HW, C, Co = 2, 6, 1030, 64, 1280
+    x5 = h(torch.randn(B, C, Fr, HW, 1, generator=g))
+    w = h(torch.randn(Co, C, 3, 1, 1, generator=g) / 14)
+    ref = F.conv3d(x5, w, None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, Co)
+    rows = x5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, C).contiguous()
+    close(ops.gemm(d(rows), d(packing.pack_tconv3(w)), M=B * Fr * HW, mode=ops.TCONV3, tconv=(Fr, HW)), ref)
+
+
 def test_gemm_two_sources_and_strided_views(gpu):
     ops, _ = _ops()
     g = torch.Generator().manual_seed(5)
@@ -264,7 +304,7 @@ def test_conv_in_and_output_permute(gpu):
     b = h(torch.randn(Cout, generator=g) * 0.1)
     x4 = x.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cin, H, W)
     ref = packing.nchw_to_rows(F.conv2d(x4, w, b, padding=1))
-    out = ops.conv_in(x.half().to(gpu), w.permute(0, 2, 3, 1).contiguous().half().to(gpu), b.half().to(gpu))
+    out = ops.conv_in(x.half().to(gpu), packing.pack_conv_in(w.half()).to(gpu), b.half().to(gpu))
     close(out, ref)
     # rows -> (B,C,F,H,W) takes the first C columns
     back = ops.rows_to_ncfhw(out, B, 4, Fr, H, W)
