@@ -85,6 +85,8 @@ def main():
     F, H, W = args.frames, 72, 128
     cfg = UNet3DConfig.zeroscope()
     unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
+    if world > 1:
+        unet.shard_(rank, world)       # hybrid mode: 1/N of every unit per GPU, per-unit RCCL all-gather
     sched = DDIMScheduler()
     sched.set_timesteps(50, device=dev)
     if world == 1:
@@ -96,7 +98,8 @@ def main():
         ranges = cp.for_rank(rank)
         assert len(ranges) == 1 and ranges[0][1] - ranges[0][0] == F, (cp, ranges)
         workload = (f"Zeroscope_v2_XL UNet3D, {T}-frame video as {world} windows of {F} frames (chunk {F}, overlap 4, "
-                    f"hybrid_ctx), one window per GPU, CFG batch 2")
+                    f"hybrid_ctx), one window per GPU, CFG batch 2, UNet parameters sharded 1/{world} per GPU "
+                    f"with per-unit RCCL all-gather prefetch")
     base = seeded_noise((1, 4, T, H, W), sched.init_noise_sigma, dev)
     if world > 1:
         ctx = base.mean(dim=2, keepdim=True).contiguous()

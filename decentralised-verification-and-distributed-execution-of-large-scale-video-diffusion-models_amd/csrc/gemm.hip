@@ -18,20 +18,8 @@
 // LDS is double-buffered with ONE barrier per K-tile: tile k+1 streams in while tile k feeds the
 // MFMAs.  The MFMA is issued with the weight fragment as the A operand, so a lane ends up holding
 // 8 consecutive output channels of one row -> 16-byte epilogue stores.
-#include "vdx_common.h"
-
-struct GemmP {
-    const f16 *a, *a2, *w, *bias, *bias2, *res;
-    f16* out;
-    int M, N, K, c1, c2;
-    int lda, lda2, ldo, ldr;
-    int h_in, w_in, h_out, w_out, stride, ups;
-    int frames, hw, rpb2, ldb2;
-    int ntn;
-};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+#include "gemm_common.h"
+#include <stdlib.h>
 
 template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
@@ -184,50 +172,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         __syncthreads();                  // next tile landed (vmcnt(0)) and this one is fully read
     }
 
-    // ---- epilogue: lane holds rows m = ..+frow, 8 consecutive columns per accumulator pair --
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + frow;
-        if (m >= p.M) continue;
-        const f16* b2row = p.bias2 ? p.bias2 + (size_t)(m / p.rpb2) * p.ldb2 : nullptr;
-#pragma unroll
-        for (int a = 0; a < TN / 2; ++a) {
-            const int n = n0 + wn * WTN + a * 32 + fq * 8;
-            if (n >= p.N) continue;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = acc[i][2 * a][j];
-                v[4 + j] = acc[i][2 * a + 1][j];
-            }
-            if (p.bias) {
-                const f16x8 b = *(const f16x8*)(p.bias + n);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
-            }
-            if (GEGLU) {
-                f16x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (f16)(v[j] * gelu_erf_f(v[4 + j]));
-                *(f16x4*)(p.out + (size_t)m * p.ldo + (n >> 1)) = o;
-            } else {
-                if (b2row) {
-                    const f16x8 b = *(const f16x8*)(b2row + n);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
-                }
-                if (p.res) {
-                    const f16x8 r = *(const f16x8*)(p.res + (size_t)m * p.ldr + n);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
-                }
-                f16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-                *(f16x8*)(p.out + (size_t)m * p.ldo + n) = o;
-            }
-        }
-    }
+    gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * WTM, n0 + wn * WTN, frow, fq);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -248,16 +193,32 @@ static int launch(const GemmP& p, hipStream_t st) {
     return vdx_launch_status("vdx_gemm_f16");
 }
 
+// Kernel choice.  `force` (vdx_gemm_args.epilogue bits 8..11, a testing/tuning knob) pins a
+// variant: 1 = 128x128 two-stage, 2 = 256x320 two-stage (K-step 64), 3 = 256x320 four-stage ring
+// (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 5 = 256x64.
 template <int MODE, bool GEGLU>
-static int pick_tile(const GemmP& p, hipStream_t st) {
-    // 128x128 tiles everywhere (N tails such as 320 = 2.5 tiles are masked: still faster than the
-    // 256x64 shape, profiles/r01_first_path_kernel_stats.csv); 256x64 only for a 64-wide output.
-    // Channel widths of this UNet are multiples of 320: a 256x320 tile (8 waves, 64x160 per wave,
-    // 144 KB of LDS, one block per CU) halves LDS/L2 bytes per MFMA against 128x128.
-    if (p.N % 320 == 0 && (long long)((p.M + 255) / 256) * (p.N / 320) >= 192)
-        return launch<256, 320, 4, 2, MODE, GEGLU>(p, st);
-    if (p.N > 64) return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
-    return launch<256, 64, 4, 1, MODE, GEGLU>(p, st);
+static int pick_tile(const GemmP& p, int force, hipStream_t st) {
+    int v = force;
+    if (v == 0) {
+        // Channel widths of this UNet are multiples of 320: the 320-wide tiles (64x160 per wave)
+        // halve LDS/L2 bytes per MFMA against 128x128.  Measured per shape (tools/gemm_bench.py,
+        // profiles/r01_gemm_variants.txt): the 256x320 two-stage K-64 kernel wins whenever its grid
+        // fills the chip; for the small-M level-3 shapes the 128x320 kernel (twice the blocks)
+        // wins; K-32 rings lose to K-64 on every large shape.
+        const long long t256 = (long long)((p.M + 255) / 256) * (p.N / 320);
+        const long long t128 = (long long)((p.M + 127) / 128) * (p.N / 320);
+        if (p.N % 320 == 0 && t256 >= 192) v = 2;
+        else if (p.N % 320 == 0 && t128 >= 160) v = 4;
+        else v = p.N > 64 ? 1 : 5;
+    }
+    switch (v) {
+        case 1: return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
+        case 2: return launch<256, 320, 4, 2, MODE, GEGLU>(p, st);
+        case 3: return vdx_gemm_ring_launch(p, MODE, GEGLU, 0, st);
+        case 4: return vdx_gemm_ring_launch(p, MODE, GEGLU, 1, st);
+        case 5: return launch<256, 64, 4, 1, MODE, GEGLU>(p, st);
+    }
+    return vdx_fail("gemm: unknown kernel variant %d", v);
 }
 
 extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
@@ -286,14 +247,15 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
     p.ntn = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool geglu = (a->epilogue & VDX_EPI_GEGLU) != 0;
+    const int force = (a->epilogue >> 8) & 15;   // kernel variant override (0 = automatic)
     if (geglu) {
         VDX_CHECK(a->mode == VDX_GEMM_PLAIN && !a->bias2 && !a->residual, "gemm: GEGLU epilogue is plain-mode only");
         VDX_CHECK(a->ldo % 4 == 0, "gemm: GEGLU ldo must be a multiple of 4");
-        return pick_tile<0, true>(p, st);
+        return pick_tile<0, true>(p, force, st);
     }
     switch (a->mode) {
         case VDX_GEMM_PLAIN:
-            return pick_tile<0, false>(p, st);
+            return pick_tile<0, false>(p, force, st);
         case VDX_GEMM_CONV3X3:
             VDX_CHECK(a->c2 == 0, "gemm: conv3x3 takes one source");
             VDX_CHECK(a->stride == 1 || a->stride == 2, "gemm: stride %d", a->stride);
@@ -304,11 +266,11 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
                 VDX_CHECK(a->h_out == (he + 2 - 3) / a->stride + 1 && a->w_out == (we + 2 - 3) / a->stride + 1,
                           "gemm: conv output %dx%d inconsistent with input %dx%d stride %d", a->h_out, a->w_out, he, we, a->stride);
             }
-            return pick_tile<1, false>(p, st);
+            return pick_tile<1, false>(p, force, st);
         case VDX_GEMM_TCONV3:
             VDX_CHECK(a->c2 == 0, "gemm: tconv3 takes one source");
             VDX_CHECK(a->frames > 0 && a->hw > 0 && a->M % (a->frames * a->hw) == 0, "gemm: tconv geometry M=%d F=%d HW=%d", a->M, a->frames, a->hw);
-            return pick_tile<2, false>(p, st);
+            return pick_tile<2, false>(p, force, st);
     }
     return vdx_fail("gemm: unknown mode %d", a->mode);
 }

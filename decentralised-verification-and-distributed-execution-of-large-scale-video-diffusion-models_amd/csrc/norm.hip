@@ -25,11 +25,11 @@ __device__ __forceinline__ f16x8 gn_load(const GnP& p, size_t row, int cv) {
 }
 
 __global__ void gn_partial_kernel(const GnP p) {
-    extern __shared__ float gsum[];  // [G][2]
+    // [2][krows][C] per-thread channel sums; reduced to groups in a FIXED order (no float atomics:
+    // the statistics, and therefore every output of the network, are bitwise reproducible)
+    extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int sample = blockIdx.y, slab = blockIdx.x;
-    for (int i = tid; i < 2 * p.G; i += blockDim.x) gsum[i] = 0.f;
-    __syncthreads();
     const int cv = tid % p.nvec, rsub = tid / p.nvec;
     float s[8], ss[8];
 #pragma unroll
@@ -44,15 +44,22 @@ __global__ void gn_partial_kernel(const GnP p) {
             ss[j] += f * f;
         }
     }
+    const int plane = p.krows * p.C;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int g = (cv * 8 + j) / p.cpg;
-        atomicAdd(&gsum[2 * g], s[j]);
-        atomicAdd(&gsum[2 * g + 1], ss[j]);
+        lds[rsub * p.C + cv * 8 + j] = s[j];
+        lds[plane + rsub * p.C + cv * 8 + j] = ss[j];
     }
     __syncthreads();
     float* dst = p.partial + ((size_t)sample * p.nslabs + slab) * 2 * p.G;
-    for (int i = tid; i < 2 * p.G; i += blockDim.x) dst[i] = gsum[i];
+    for (int i = tid; i < 2 * p.G; i += blockDim.x) {
+        const int g = i >> 1;
+        const float* src = lds + (i & 1) * plane + g * p.cpg;
+        float acc = 0.f;
+        for (int r = 0; r < p.krows; ++r)
+            for (int c = 0; c < p.cpg; ++c) acc += src[r * p.C + c];
+        dst[i] = acc;
+    }
 }
 
 // one wave per (sample, group): combine slab partials in double, emit per-channel scale/shift
@@ -146,7 +153,7 @@ extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2,
     const int nt = gn_threads(p.nvec, &p.krows);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.nslabs, n_samples);
-    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), 2 * G * sizeof(float), st, p);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), 2 * (size_t)p.krows * C * sizeof(float), st, p);
     const int nsg = n_samples * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, st, p, (const f16*)gamma, (const f16*)beta, eps);
     if (silu)

@@ -49,7 +49,7 @@ def round_up(x: int, m: int) -> int:
 
 # --------------------------------------------------------------------------------------------
 def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=0, residual=None,
-         out=None, geglu=False, conv=None, tconv=None):
+         out=None, geglu=False, conv=None, tconv=None, variant=0):
     """out[M][N] = epi(gather(a|a2)[M][K] @ w[N][K]^T).  See include/vdx.h `vdx_gemm_args`."""
     lib = _lib.load()
     ar, c1, lda = _rows(a, "a")
@@ -103,7 +103,7 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     g.bias, g.bias2, g.residual, g.out = _p(bias, "bias"), _p(bias2, "bias2"), _p(residual, "residual"), _p(out, "out")
     g.M, g.N, g.K, g.mode, g.c1, g.c2 = M, N, K, mode, c1, c2
     g.lda, g.ldo = lda, ldo
-    g.epilogue = EPI_GEGLU if geglu else 0
+    g.epilogue = (EPI_GEGLU if geglu else 0) | ((variant & 15) << 8)   # variant: kernel override (tests/tuning)
     if PROFILE is None:
         _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
         return out
@@ -112,20 +112,28 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     ev0.record()
     _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
     ev1.record()
-    PROFILE.append((gemm_kernel_name(M, N, mode, geglu), 2.0 * M * N * K, ev0, ev1))
+    PROFILE.append((gemm_kernel_name(M, N, K, mode, geglu, variant), 2.0 * M * N * K, ev0, ev1))
     return out
 
 
 PROFILE = None   # set to a list by bench.py to collect (kernel name, algorithmic FLOPs, start, end)
 
 
-def gemm_kernel_name(M: int, N: int, mode: int, geglu: bool) -> str:
+def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: int = 0) -> str:
     """Name of the instantiation gemm.hip's pick_tile() launches (as rocprofv3 prints it)."""
-    if N % 320 == 0 and ((M + 255) // 256) * (N // 320) >= 192:
-        tile = "256, 320, 4, 2"
-    else:
-        tile = "128, 128, 2, 2" if N > 64 else "256, 64, 4, 1"
-    return f"gemm_kernel<{tile}, {0 if geglu else mode}, {'true' if geglu else 'false'}>"
+    v = variant
+    if v == 0:
+        t256 = ((M + 255) // 256) * (N // 320)
+        t128 = ((M + 127) // 128) * (N // 320)
+        if N % 320 == 0 and t256 >= 192:
+            v = 2
+        elif N % 320 == 0 and t128 >= 160:
+            v = 4
+        else:
+            v = 1 if N > 64 else 5
+    tail = f"{0 if geglu else mode}, {'true' if geglu else 'false'}>"
+    return {1: "gemm_kernel<128, 128, 2, 2, ", 2: "gemm_kernel<256, 320, 4, 2, ", 3: "gemm_ring_kernel<4, 4, ",
+            4: "gemm_ring_kernel<2, 2, ", 5: "gemm_kernel<256, 64, 4, 1, "}[v] + tail
 
 
 def conv_in(x, w, bias, out=None):

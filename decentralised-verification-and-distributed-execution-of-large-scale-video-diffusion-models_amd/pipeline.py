@@ -38,6 +38,10 @@ class DiffuserConfig:
     overlap_rule: str = "coherent"
 
     @property
+    def use_fsdp(self):
+        return self.mode in ("fsdp", "hybrid", "hybrid_ctx")
+
+    @property
     def no_chunking(self):
         return self.mode == "fsdp"
 
@@ -101,6 +105,9 @@ class DistributedVideoDiffuser:
         self.rank, self.world = _world()
         self.unet, self.scheduler = unet, scheduler
         self.uncond_emb, self.cond_emb = uncond_emb, cond_emb
+        # reference :63-78 — modes fsdp / hybrid / hybrid_ctx shard the UNet's parameters
+        if cfg.use_fsdp and self.world > 1 and isinstance(getattr(unet, "W", None), dict):
+            unet.shard_(self.rank, self.world)
         scheduler.set_timesteps(cfg.steps, device=cfg.device)
         self.ctx = None
         if cfg.use_ctx:                                               # reference :105-127

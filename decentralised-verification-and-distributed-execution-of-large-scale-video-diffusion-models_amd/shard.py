@@ -1,0 +1,149 @@
+"""Per-unit parameter sharding with prefetching all-gather — the MI355X-native counterpart of the
+reference's `FSDP(pipe.unet, FULL_SHARD, ...)` wrap (`fsdp_chunked_coherent.py:63-88`).
+
+Every *unit* (one resnet, one temporal-conv stack, one spatial or temporal transformer, one
+resampler) owns a flat fp16 buffer; each GPU keeps 1/world of it.  During a forward the units are
+used strictly in order (`UNet3DConditionModel.unit_schedule`), so while unit k computes, unit k+1
+is all-gathered (RCCL over xGMI, `torch.distributed`) on a side HIP stream into the other of two
+gather buffers; a buffer is only overwritten after the compute stream has passed the unit that
+used it.  Inference only: no reduce-scatter.  Sharding changes memory, never results.
+
+The store is a read-only mapping (name -> tensor view) and is what `UNet3DConditionModel.W`
+becomes after `shard_()`.  Works on CPU tensors with the `gloo` backend (used by the tests).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+ALIGN = 64          # elements: keeps every view 128-byte aligned
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ShardedStore:
+    def __init__(self, tensors: Dict[str, torch.Tensor], unit_of: Callable[[str], Optional[str]],
+                 schedule: List[str], rank: int, world: int, group=None):
+        """`unit_of(name)` -> unit id, or None for tensors kept replicated (small stem tensors)."""
+        self.rank, self.world, self.group = rank, world, group
+        self.schedule = list(schedule)
+        self._pos = {u: i for i, u in enumerate(self.schedule)}
+        self.replicated: Dict[str, torch.Tensor] = {}
+        self._layout: Dict[str, List] = {u: [] for u in self.schedule}     # unit -> [(name, off, shape)]
+        self._unit_of: Dict[str, str] = {}
+        sizes = {u: 0 for u in self.schedule}
+        any_t = next(iter(tensors.values()))
+        self.device, self.dtype = any_t.device, any_t.dtype
+        for name, t in tensors.items():
+            u = unit_of(name)
+            if u is None:
+                self.replicated[name] = t
+                continue
+            if u not in sizes:
+                raise KeyError(f"tensor {name!r} maps to unit {u!r} which is not in the schedule")
+            self._layout[u].append((name, sizes[u], tuple(t.shape)))
+            self._unit_of[name] = u
+            sizes[u] += _round_up(t.numel(), ALIGN)
+        self._padded = {u: _round_up(max(n, 1), ALIGN * world) for u, n in sizes.items()}
+        # local shards
+        self.shards: Dict[str, torch.Tensor] = {}
+        for u in self.schedule:
+            flat = torch.zeros(self._padded[u], dtype=self.dtype, device=self.device)
+            for name, off, shape in self._layout[u]:
+                flat[off:off + tensors[name].numel()] = tensors[name].reshape(-1)
+            n = self._padded[u] // world
+            self.shards[u] = flat[rank * n:(rank + 1) * n].clone()
+            del flat
+        cap = max(self._padded.values())
+        self._bufs = [torch.empty(cap, dtype=self.dtype, device=self.device) for _ in range(2)]
+        self._resident = [None, None]          # unit held by each buffer
+        self._ready = [None, None]             # event: gather into buffer finished
+        self._released = [None, None]          # event: compute stream is past the unit in that buffer
+        self._views: Dict[str, torch.Tensor] = {}
+        self._current: Optional[str] = None
+        self._cuda = self.device.type == "cuda"
+        self._side = torch.cuda.Stream(device=self.device) if self._cuda else None
+        self.gathers = 0
+
+    # ---- mapping protocol -------------------------------------------------------------------
+    def __contains__(self, name):
+        return name in self._unit_of or name in self.replicated
+
+    def __getitem__(self, name):
+        t = self.replicated.get(name)
+        if t is not None:
+            return t
+        u = self._unit_of[name]
+        if u != self._current:
+            self._switch_to(u)
+        return self._views[name]
+
+    def keys(self):
+        return list(self.replicated) + list(self._unit_of)
+
+    def local_bytes(self) -> int:
+        es = torch.empty(0, dtype=self.dtype).element_size()
+        return (sum(s.numel() for s in self.shards.values()) + sum(t.numel() for t in self.replicated.values())
+                + sum(b.numel() for b in self._bufs)) * es
+
+    # ---- gather machinery -------------------------------------------------------------------
+    def _gather_into(self, slot: int, unit: str):
+        """Enqueue the all-gather of `unit` into buffer `slot` (side stream on GPU)."""
+        n = self._padded[unit]
+        out = self._bufs[slot][:n]
+        shard = self.shards[unit]
+
+        def run():
+            if self.world == 1:
+                out.copy_(shard)
+            elif self._cuda:
+                dist.all_gather_into_tensor(out, shard, group=self.group)
+            else:
+                dist.all_gather(list(out.chunk(self.world)), shard, group=self.group)
+
+        if self._cuda:
+            with torch.cuda.stream(self._side):
+                if self._released[slot] is not None:
+                    self._side.wait_event(self._released[slot])     # old contents no longer needed
+                run()
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            self._ready[slot] = ev
+        else:
+            run()
+        self._resident[slot] = unit
+        self.gathers += 1
+
+    def _switch_to(self, unit: str):
+        # release the buffer of the unit we are leaving
+        if self._current is not None and self._cuda:
+            old = self._resident.index(self._current)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._released[old] = ev
+        if unit in self._resident:
+            slot = self._resident.index(unit)
+        else:                                                   # not prefetched: gather on demand
+            cur = self._resident.index(self._current) if self._current in self._resident else 1
+            slot = cur ^ 1                                      # keep the just-released buffer for the prefetch
+            self._gather_into(slot, unit)
+        if self._cuda and self._ready[slot] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
+        buf = self._bufs[slot]
+        self._views = {name: buf[off:off + _numel(shape)].view(shape) for name, off, shape in self._layout[unit]}
+        self._current = unit
+        # prefetch the next unit of the schedule into the other buffer
+        nxt = self.schedule[(self._pos[unit] + 1) % len(self.schedule)]
+        if nxt != unit and nxt not in self._resident:
+            self._gather_into(slot ^ 1, nxt)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n

@@ -213,14 +213,66 @@ class UNet3DConditionModel(nn.Module):
     def _apply(self, fn, recurse=True):
         # nn.Module.to()/cuda()/half(): move the packed store (floating tensors stay fp16)
         out = super()._apply(fn, recurse)
-        if self.W:
+        if isinstance(self.W, dict) and self.W:
             probe = fn(torch.empty(0, dtype=torch.float16, device=self._device))
             self.W = {k: v.to(probe.device) for k, v in self.W.items()}
             self._device = probe.device
         return out
 
     def num_parameters(self) -> int:
-        return sum(v.numel() for v in self.W.values())
+        return sum(self.W[k].numel() for k in self.W.keys())
+
+    # ------------------------------------------------------------------------------------------
+    # parameter sharding (reference: FSDP wrap, fsdp_chunked_coherent.py:63-88)
+    # ------------------------------------------------------------------------------------------
+    def unit_schedule(self) -> List[str]:
+        """Shard units in the order `forward` uses them (one gather per unit per step)."""
+        c = self.cfg
+        units = ["transformer_in"]
+
+        def layer(p, j, attn):
+            units.append(f"{p}.resnets.{j}")
+            units.append(f"{p}.temp_convs.{j}")
+            if attn:
+                units.append(f"{p}.attentions.{j}")
+                units.append(f"{p}.temp_attentions.{j}")
+
+        nlev = len(c.block_out_channels)
+        for i, t in enumerate(c.down_block_types):
+            for j in range(c.layers_per_block):
+                layer(f"down_blocks.{i}", j, t.startswith("CrossAttn"))
+            if i != nlev - 1:
+                units.append(f"down_blocks.{i}.downsamplers.0")
+        units += ["mid_block.resnets.0", "mid_block.temp_convs.0", "mid_block.attentions.0",
+                  "mid_block.temp_attentions.0", "mid_block.resnets.1", "mid_block.temp_convs.1"]
+        for i, t in enumerate(c.up_block_types):
+            for j in range(c.layers_per_block + 1):
+                layer(f"up_blocks.{i}", j, t.startswith("CrossAttn"))
+            if i != nlev - 1:
+                units.append(f"up_blocks.{i}.upsamplers.0")
+        return units
+
+    @staticmethod
+    def unit_of(name: str) -> Optional[str]:
+        """Packed-tensor name -> shard unit (None = small stem tensor kept replicated)."""
+        parts = name.split(".")
+        if parts[0] == "transformer_in":
+            return "transformer_in"
+        if parts[0] in ("down_blocks", "up_blocks"):
+            return ".".join(parts[:4])          # <block>.<i>.<kind>.<j>
+        if parts[0] == "mid_block":
+            return ".".join(parts[:3])
+        return None                              # conv_in/out, time embedding, conv_norm_out
+
+    def shard_(self, rank: int, world: int, group=None):
+        """Keep 1/world of every unit on this GPU; gather per unit with prefetch (vdx/shard.py)."""
+        from .shard import ShardedStore
+        if not isinstance(self.W, dict):
+            raise VdxError("weights are already sharded")
+        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group)
+        if self._device.type == "cuda":
+            torch.cuda.empty_cache()
+        return self
 
     # ------------------------------------------------------------------------------------------
     # building blocks (all on row matrices)
@@ -330,8 +382,9 @@ class UNet3DConditionModel(nn.Module):
             raise VdxError("UNet3DConditionModel.forward needs GPU tensors: the path has no CPU fallback")
         c, W = self.cfg, self.W
         dev = sample.device
-        if next(iter(W.values())).device != dev:
-            raise VdxError(f"weights are on {next(iter(W.values())).device}, input on {dev}")
+        wdev = self._device
+        if wdev.type != dev.type or (wdev.index is not None and dev.index is not None and wdev.index != dev.index):
+            raise VdxError(f"weights are on {wdev}, input on {dev}")
         B, Cin, F, H, Wd = sample.shape
         if Cin != c.in_channels:
             raise VdxError(f"sample has {Cin} channels, model expects {c.in_channels}")

@@ -59,9 +59,10 @@ def test_gemm_plain(gpu, M, N, K, flags):
     close(out, ref)
 
 
-def test_gemm_big_tile_all_modes(gpu):
-    """Shapes large enough (>= 192 tiles of 256x320) to take the 8-wave 256x320 kernel in every mode,
-    with M tails (M % 256 != 0)."""
+@pytest.mark.parametrize("variant", [0, 2, 3, 4])
+def test_gemm_320_wide_kernels_all_modes(gpu, variant):
+    """The 320-wide kernels in every gather mode, with M tails: variant 2 = 256x320 two-stage,
+    3 = 256x320 four-stage ring (counted vmcnt), 4 = 128x320 two blocks per CU, 0 = automatic choice."""
     ops, packing = _ops()
     g = torch.Generator().manual_seed(77)
     d = lambda t: t.half().to(gpu)
@@ -70,8 +71,9 @@ def test_gemm_big_tile_all_modes(gpu):
     a1, a2 = h(torch.randn(M, c1, generator=g)), h(torch.randn(M, c2, generator=g))
     w = h(torch.randn(N, c1 + c2, generator=g) / 11)
     b, res = h(torch.randn(N, generator=g)), h(torch.randn(M, N, generator=g))
-    assert ops.gemm_kernel_name(M, N, 0, False).startswith("gemm_kernel<256, 320")
-    close(ops.gemm(d(a1), d(w), M=M, a2=d(a2), bias=d(b), residual=d(res)), torch.cat([a1, a2], 1) @ w.t() + b + res)
+    assert "320" in ops.gemm_kernel_name(M, N, c1 + c2, 0, False) or "<2, 2" in ops.gemm_kernel_name(M, N, c1 + c2, 0, False)
+    close(ops.gemm(d(a1), d(w), M=M, a2=d(a2), bias=d(b), residual=d(res), variant=variant),
+          torch.cat([a1, a2], 1) @ w.t() + b + res)
     # GEGLU: C = 320 -> N = 2560
     M, C = 6200, 320
     x = h(torch.randn(M, C, generator=g))
@@ -79,24 +81,23 @@ def test_gemm_big_tile_all_modes(gpu):
     bb = h(torch.randn(8 * C, generator=g) * 0.1)
     a_, g_ = (x @ w.t() + bb).chunk(2, dim=-1)
     wp, bp = packing.pack_geglu(w.half(), bb.half())
-    assert ops.gemm_kernel_name(M, 8 * C, 0, True).startswith("gemm_kernel<256, 320")
-    close(ops.gemm(d(x), wp.to(gpu), M=M, bias=bp.to(gpu), geglu=True), a_ * F.gelu(g_))
-    # conv3x3 with temb bias: 3 images of 63x65, 64 -> 1280
-    n, hh, ww, cin, cout = 3, 63, 65, 64, 1280
-    x = h(torch.randn(n, cin, hh, ww, generator=g))
-    w = h(torch.randn(cout, cin, 3, 3, generator=g) / 24)
-    temb = h(torch.randn(n, cout, generator=g))
-    ref = packing.nchw_to_rows(F.conv2d(x, w, None, padding=1) + temb[:, :, None, None])
-    assert ops.gemm_kernel_name(n * hh * ww, cout, 1, False).startswith("gemm_kernel<256, 320")
-    close(ops.gemm(d(packing.nchw_to_rows(x)), d(packing.pack_conv3x3(w)), M=n * hh * ww, mode=ops.CONV3X3,
-                   bias2=d(temb), rows_per_bias2=hh * ww, conv=(n, hh, ww, hh, ww, 1, False)), ref)
+    close(ops.gemm(d(x), wp.to(gpu), M=M, bias=bp.to(gpu), geglu=True, variant=variant), a_ * F.gelu(g_))
+    # conv3x3 with temb bias: 3 images of 63x65, 64 -> 1280, and a long-K one (K = 9*256 = 2304)
+    for cin, cout in ((64, 1280), (256, 640)):
+        n, hh, ww = 3, 63, 65
+        x = h(torch.randn(n, cin, hh, ww, generator=g))
+        w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+        temb = h(torch.randn(n, cout, generator=g))
+        ref = packing.nchw_to_rows(F.conv2d(x, w, None, padding=1) + temb[:, :, None, None])
+        close(ops.gemm(d(packing.nchw_to_rows(x)), d(packing.pack_conv3x3(w)), M=n * hh * ww, mode=ops.CONV3X3,
+                       bias2=d(temb), rows_per_bias2=hh * ww, conv=(n, hh, ww, hh, ww, 1, False), variant=variant), ref)
     # temporal conv: B=2, F=6, HW=1030, 64 -> 1280
     B, Fr, HW, C, Co = 2, 6, 1030, 64, 1280
     x5 = h(torch.randn(B, C, Fr, HW, 1, generator=g))
     w = h(torch.randn(Co, C, 3, 1, 1, generator=g) / 14)
     ref = F.conv3d(x5, w, None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, Co)
     rows = x5[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * HW, C).contiguous()
-    close(ops.gemm(d(rows), d(packing.pack_tconv3(w)), M=B * Fr * HW, mode=ops.TCONV3, tconv=(Fr, HW)), ref)
+    close(ops.gemm(d(rows), d(packing.pack_tconv3(w)), M=B * Fr * HW, mode=ops.TCONV3, tconv=(Fr, HW), variant=variant), ref)
 
 
 def test_gemm_two_sources_and_strided_views(gpu):
