@@ -7,10 +7,14 @@
 A *step* = one iteration of `fsdp_chunked_coherent.py:132-142` for the chunk a rank owns:
 cat/ctx-inject -> UNet3D forward on the CFG batch of 2 -> guidance combine -> DDIM update.
 N=1 : BASELINE config[1] — Zeroscope-XL, 24 frames @ 576x1024 (latent 72x128), monolithic.
-N>1 : weak scaling over frame chunks — a (20*N+4)-frame video planned with chunk 24 / overlap 4
-      gives exactly N 24-frame windows, one per rank (reference planner + round-robin, :149-184);
-      no data-path collective inside the step; ctx broadcast before and chunk gather after the
-      loop are outside the timed steps.  value = N * steps / max-over-ranks time.
+N>1 : weak scaling over frame chunks — a 20*N-frame video planned with chunk 24 / overlap 4 by
+      the reference planner gives exactly N windows, one per rank (round-robin, :149-184): N-1 of
+      24 frames and, as the reference planner always does with an overlap, a shorter last one
+      (20 frames).  UNet parameters are sharded 1/N per GPU (per-unit RCCL all-gather, prefetched on
+      a side stream); no other collective inside the step; ctx broadcast before and chunk gather
+      after the loop are outside the timed steps.
+      value = (frames all ranks denoise per step / 24) * steps / max-over-ranks time,
+      i.e. 24-frame-equivalent steps per second (FLOPs are linear in the frame count).
 Weights are synthetic (diffusers-shaped, seeded); inputs are synthetic noise/text embeddings.
 Prints ONE JSON line on rank 0.
 """
@@ -61,8 +65,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=24, help="frames per chunk (default: BASELINE 24)")
     ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--shapes", type=int, default=0, help="also list the top-N GEMM shapes by time (dev aid)")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="N=1 only: run the multi-GPU code path (RCCL init, sharded weights, collectives) with world 1")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE JSON line: libraries that print to fd 1 (RCCL's version banner)
+    # are sent to stderr for the whole run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -71,8 +84,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    dist_mode = world > 1 or args.rehearse_dist
+    if dist_mode:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")      # keep RCCL's version banner off stdout (one JSON line)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if args.rehearse_dist:
+            os.environ["VDX_SHARD_FORCE_COLLECTIVE"] = "1"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import vdx  # noqa: F401
     from vdx import ops
@@ -85,23 +104,24 @@ def main():
     F, H, W = args.frames, 72, 128
     cfg = UNet3DConfig.zeroscope()
     unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
-    if world > 1:
+    if dist_mode:
         unet.shard_(rank, world)       # hybrid mode: 1/N of every unit per GPU, per-unit RCCL all-gather
     sched = DDIMScheduler()
     sched.set_timesteps(50, device=dev)
-    if world == 1:
+    if not dist_mode:
         T, ranges, ctx = F, [(0, F)], None
         workload = f"Zeroscope_v2_XL UNet3D, {F} frames @576x1024 (latent {H}x{W}), CFG batch 2, monolithic, 1 GPU"
     else:
-        T = (F - 4) * world + 4
+        T = (F - 4) * world
         cp = plan(T, world, chunk_size=F, overlap=4)
         ranges = cp.for_rank(rank)
-        assert len(ranges) == 1 and ranges[0][1] - ranges[0][0] == F, (cp, ranges)
-        workload = (f"Zeroscope_v2_XL UNet3D, {T}-frame video as {world} windows of {F} frames (chunk {F}, overlap 4, "
-                    f"hybrid_ctx), one window per GPU, CFG batch 2, UNet parameters sharded 1/{world} per GPU "
-                    f"with per-unit RCCL all-gather prefetch")
+        if len(cp.ranges) != world or len(ranges) != 1:
+            raise SystemExit(f"planner gave {cp.ranges} for T={T}, world={world}")
+        workload = (f"Zeroscope_v2_XL UNet3D, {T}-frame video as {world} windows (chunk {F}, overlap 4, hybrid_ctx: "
+                    f"{world - 1} x {F} frames + 1 x {F - 4}), one window per GPU, CFG batch 2, UNet parameters "
+                    f"sharded 1/{world} per GPU with per-unit RCCL all-gather prefetch")
     base = seeded_noise((1, 4, T, H, W), sched.init_noise_sigma, dev)
-    if world > 1:
+    if dist_mode:
         ctx = base.mean(dim=2, keepdim=True).contiguous()
         dist.broadcast(ctx, src=0)
     s, e = ranges[0]
@@ -122,7 +142,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,13 +158,14 @@ def main():
     finite = bool(torch.isfinite(lat.float()).all())
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     tt = torch.tensor([dt, peak_gb], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_mode:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, peak_gb = float(tt[0]), float(tt[1])
 
     if rank == 0:
         tf_step = TFLOP_PER_STEP_24F * F / 24.0
-        sps = world * args.steps / dt
+        total_frames = F if not dist_mode else sum(e_ - s_ for s_, e_ in cp.ranges)
+        sps = (total_frames / F) * args.steps / dt
         out = {
             "metric": "denoising steps/sec, Zeroscope-XL 24f@1024x576 (CFG UNet3D forward + guidance + DDIM)",
             "value": round(sps, 5), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -159,11 +180,14 @@ def main():
         if prof:
             torch.cuda.synchronize()
             agg = {}
-            for name, flops, e0, e1 in prof:
-                a = agg.setdefault(name, [0.0, 0.0, 0])
-                a[0] += flops
-                a[1] += e0.elapsed_time(e1)
-                a[2] += 1
+            shapes = {}
+            for name, flops, e0, e1, mnk in prof:
+                ms_ = e0.elapsed_time(e1)
+                for d_, k_ in ((agg, name), (shapes, (name.split("<")[1][:14],) + mnk)):
+                    a = d_.setdefault(k_, [0.0, 0.0, 0])
+                    a[0] += flops
+                    a[1] += ms_
+                    a[2] += 1
             name, (fl, ms, n) = max(agg.items(), key=lambda kv: kv[1][1])
             ach = fl / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -173,17 +197,22 @@ def main():
             out["gemm_kernels"] = {k: {"launches": v[2], "ms": round(v[1], 2), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
             out["gemm_ms_per_step"] = round(sum(v[1] for v in agg.values()) / args.steps, 2)
+            if args.shapes:
+                out["gemm_shapes_ms_per_step"] = [
+                    [" ".join(str(x) for x in k), v[2] // args.steps, round(v[1] / args.steps, 2),
+                     round(v[0] / (v[1] * 1e-3) / 1e12)]
+                    for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:args.shapes]]
         else:
             ach = tf_step * args.steps / dt
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None, "kernel": "whole step"}
-        if world == 1 and args.cpu_frames > 0:
+        if world == 1 and args.cpu_frames > 0 and not args.rehearse_dist:
             del unet
             torch.cuda.empty_cache()
             ncpu = min(len(os.sched_getaffinity(0)), 16)      # the 1-GPU box's CPU share
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, ncpu)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
 

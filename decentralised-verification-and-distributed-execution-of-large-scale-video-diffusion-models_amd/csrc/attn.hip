@@ -46,13 +46,18 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     const int kvb = seq / p.seq_per_kv;
     const int q0 = blockIdx.x * 128 + wave * 32;
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane = query column ---------------------
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane = query column.  Pre-scaled by
+    // scale*log2(e) so the scores come out of the MFMA already in exp2 units.
     f16x8 qf[4];
     {
         const int qr = min(q0 + r32, p.sq - 1);
         const f16* src = p.q + ((size_t)seq * p.sq + qr) * p.ldq + head * 64 + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(src + 16 * ks);
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 raw = *(const f16x8*)(src + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ks][j] = (f16)((float)raw[j] * p.c);
+        }
     }
 
     // ---- staging descriptors: 2 K chunks + 2 V^T chunks per thread per tile ---------------
@@ -64,18 +69,33 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         st_row[i] = (i * 256 + tid) >> 3;
         st_lds[i] = st_row[i] * 128 + ((cch ^ ((st_row[i] >> 1) & 7)) << 4);
     }
-    const f16* kbase = p.k + (size_t)kvb * p.skv_pad * p.ldk + head * 64 + cch * 8;
-    const f16* vbase = p.vt + (size_t)head * 64 * p.ldvt + (size_t)kvb * p.skv_pad + cch * 8;
+    // per-thread source pointers walk forward one tile per iteration (no per-tile 64-bit address
+    // arithmetic); bounds are only checked in tiles that cross skv_pad (wave-uniform branch)
+    const f16* kptr0 = p.k + ((size_t)kvb * p.skv_pad + st_row[0]) * p.ldk + head * 64 + cch * 8;
+    const f16* kptr1 = kptr0 + (size_t)32 * p.ldk;                       // st_row[1] = st_row[0] + 32
+    const f16* vptr0 = p.vt + ((size_t)head * 64 + st_row[0]) * p.ldvt + (size_t)kvb * p.skv_pad + cch * 8;
+    const f16* vptr1 = vptr0 + (size_t)32 * p.ldvt;
+    const size_t kstep = (size_t)64 * p.ldk;
     u32x4 rk[2], rv[2];
     auto gload = [&](int t) {
         const int k0 = t * 64;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = k0 + st_row[i];
-            rk[i] = *(const u32x4*)(key < p.skv_pad ? kbase + (size_t)key * p.ldk : zp);
-            const int kc = k0 + cch * 8;  // first key of this 8-key chunk; chunks never straddle skv_pad
-            rv[i] = *(const u32x4*)(kc < p.skv_pad ? vbase + (size_t)st_row[i] * p.ldvt + k0 : zp);
+        if (k0 + 64 <= p.skv_pad) {
+            rk[0] = *(const u32x4*)kptr0;
+            rk[1] = *(const u32x4*)kptr1;
+            rv[0] = *(const u32x4*)vptr0;
+            rv[1] = *(const u32x4*)vptr1;
+        } else {                                                       // tile crosses skv_pad: zero fill
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const bool vok = k0 + cch * 8 < p.skv_pad;                   // chunks never straddle skv_pad
+            rk[0] = k0 + st_row[0] < p.skv_pad ? *(const u32x4*)kptr0 : z;
+            rk[1] = k0 + st_row[1] < p.skv_pad ? *(const u32x4*)kptr1 : z;
+            rv[0] = vok ? *(const u32x4*)vptr0 : z;
+            rv[1] = vok ? *(const u32x4*)vptr1 : z;
         }
+        kptr0 += kstep;
+        kptr1 += kstep;
+        vptr0 += 64;
+        vptr1 += 64;
     };
     auto lstore = [&](int buf) {
         char* s = smem + buf * 16384;
@@ -86,12 +106,25 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         }
     };
 
+    // Online softmax with the running maximum folded INTO the score contraction: one extra k-step
+    // multiplies a constant [1,0,..] row of "K" with a [-m,0,..] column of "Q", so S' = S - m costs
+    // one MFMA per 32 keys on the matrix pipe (which has slack here) and no per-score VALU op; in the
+    // common tile (no new maximum) p = exp2(S') directly.  m only has to be the SAME for a row's p and
+    // its row sum, so its fp16 rounding is harmless.  The VALU keeps one v_exp, half a v_max3, half a
+    // v_cvt_pk and half a v_dot2 (row sum) per score.
     f32x16 o_acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 16; ++j) o_acc[0][j] = o_acc[1][j] = 0.f;
+    float m_run = 0.f;                     // offset in use (exp2 units, fp16-representable)
+    float l_run = 0.f;                     // this lane's half of the row sum
+    f16x2 one2;
+    one2[0] = one2[1] = (f16)1.0f;
+    f16x8 e0, negm;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) o_acc[i][j] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
+    for (int j = 0; j < 8; ++j) {
+        e0[j] = (f16)((j == 0 && h == 0) ? 1.0f : 0.0f);
+        negm[j] = (f16)0.0f;
+    }
 
     const int krow = pi_row(r32);
     const int ntiles = (p.skv + 63) >> 6;
@@ -104,21 +137,37 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         const char* Ks = smem + cur * 16384;
         const char* Vs = Ks + 8192;
 
-        // ---- S^T = K . Q^T : two 32-key blocks -------------------------------------------
-        f32x16 s_acc[2];
+        // ---- S' = K . Q^T - m : two 32-key blocks.  All 8 K fragments are requested up front so
+        // the MFMA chain never waits for an LDS round trip per k-step.
+        f16x8 kf[2][4];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s_acc[kb][j] = 0.f;
             const int row = kb * 32 + krow;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int c = 2 * ks + h;
-                const f16x8 kf = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s_acc[kb], 0, 0, 0);
+                kf[kb][ks] = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
             }
         }
-        // ---- online softmax, lane-local per query ----------------------------------------
+        f32x16 s_acc[2], zero16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) zero16[j] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], ks == 0 ? zero16 : s_acc[kb], 0, 0, 0);
+            s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, negm, s_acc[kb], 0, 0, 0);   // - m
+        }
+        // V^T fragments of the first 32 keys: requested now, they land during the softmax VALU work
+        f16x8 vfa[2][2], vfb[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + r32, c = 2 * kk + h;
+                vfa[kk][db] = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
         const int k0 = t * 64;
         if (k0 + 64 > p.skv) {
 #pragma unroll
@@ -133,36 +182,59 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s_acc[kb][j]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-        const float mc = m_new * p.c;
-        m_run = m_new;
-        float rs = 0.f;
+        // tile 0 establishes the offset (may be negative); later it moves only when the row maximum
+        // grows by more than 1/16 (p then stays <= 2^(1/16): no overflow, no perpetual re-trigger)
+        const bool move = t == 0 || mx > 0.0625f;
+        if (__builtin_amdgcn_ballot_w64(move) != 0) {              // rare after the first tiles
+            const float m_new = (float)(f16)(m_run + (move ? mx : 0.f));
+            const float d = m_new - m_run;                         // shift actually applied
+            m_run = m_new;
+            negm[0] = (f16)(h == 0 ? -m_new : 0.f);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s_acc[kb][j] -= d;
+            if (t > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l_run *= alpha;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    o_acc[0][j] *= alpha;
+                    o_acc[1][j] *= alpha;
+                }
+            }
+        }
+        // p = exp2(S'), packed to fp16 pairs; row sum by v_dot2_f32_f16 against ones (half the adds)
         f16x8 pf[4];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float e = __builtin_amdgcn_exp2f(s_acc[kb][j] * p.c - mc);
-                rs += e;
-                pf[kb * 2 + (j >> 3)][j & 7] = (f16)e;
+            for (int j = 0; j < 16; j += 2) {
+                f16x2 pp;
+                pp[0] = (f16)__builtin_amdgcn_exp2f(s_acc[kb][j]);
+                pp[1] = (f16)__builtin_amdgcn_exp2f(s_acc[kb][j + 1]);
+                l_run = __builtin_amdgcn_fdot2(pp, one2, l_run, false);
+                pf[kb * 2 + (j >> 3)][j & 7] = pp[0];
+                pf[kb * 2 + (j >> 3)][(j & 7) + 1] = pp[1];
             }
-        l_run = l_run * alpha + rs;
+        // ---- O^T += V^T . P^T : second half of V^T requested before the first half is consumed ----
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) o_acc[db][j] *= alpha;
-        // ---- O^T += V^T . P^T ---------------------------------------------------------------
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const int row = db * 32 + r32;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {  // kk = 2*kb + s : keys 16*kk + 8*h .. +7
-                const int c = 2 * kk + h;
-                const f16x8 vf = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o_acc[db], 0, 0, 0);
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + r32, c = 2 * (kk + 2) + h;
+                vfb[kk][db] = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
             }
-        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfa[kk][db], pf[kk], o_acc[db], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfb[kk][db], pf[kk + 2], o_acc[db], 0, 0, 0);
         if (t + 1 < ntiles) lstore(cur ^ 1);
         __syncthreads();
     }

@@ -205,10 +205,14 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
         // profiles/r01_gemm_variants.txt): the 256x320 two-stage K-64 kernel wins whenever its grid
         // fills the chip; for the small-M level-3 shapes the 128x320 kernel (twice the blocks)
         // wins; K-32 rings lose to K-64 on every large shape.
-        const long long t256 = (long long)((p.M + 255) / 256) * (p.N / 320);
-        const long long t128 = (long long)((p.M + 127) / 128) * (p.N / 320);
-        if (p.N % 320 == 0 && t256 >= 192) v = 2;
-        else if (p.N % 320 == 0 && t128 >= 160) v = 4;
+        // Widths that are not multiples of 320 (transformer_in: 512/1536/4096) still take the 320-wide
+        // tile when the masked tail wastes < 25 % of the last column of tiles.
+        const int nt320 = (p.N + 319) / 320;
+        const bool fits = nt320 * 320 * 4 <= p.N * 5 && p.M >= 1024;   // (swapped V^T products have M = C)
+        const long long t256 = (long long)((p.M + 255) / 256) * nt320;
+        const long long t128 = (long long)((p.M + 127) / 128) * nt320;
+        if (fits && t256 >= 192) v = 2;
+        else if (fits && t128 >= 160) v = 4;
         else v = p.N > 64 ? 1 : 5;
     }
     switch (v) {

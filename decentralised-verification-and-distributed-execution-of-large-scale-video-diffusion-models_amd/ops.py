@@ -112,7 +112,7 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     ev0.record()
     _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
     ev1.record()
-    PROFILE.append((gemm_kernel_name(M, N, K, mode, geglu, variant), 2.0 * M * N * K, ev0, ev1))
+    PROFILE.append((gemm_kernel_name(M, N, K, mode, geglu, variant), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
 
@@ -123,11 +123,13 @@ def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: in
     """Name of the instantiation gemm.hip's pick_tile() launches (as rocprofv3 prints it)."""
     v = variant
     if v == 0:
-        t256 = ((M + 255) // 256) * (N // 320)
-        t128 = ((M + 127) // 128) * (N // 320)
-        if N % 320 == 0 and t256 >= 192:
+        nt320 = (N + 319) // 320
+        fits = nt320 * 320 * 4 <= N * 5 and M >= 1024
+        t256 = ((M + 255) // 256) * nt320
+        t128 = ((M + 127) // 128) * nt320
+        if fits and t256 >= 192:
             v = 2
-        elif N % 320 == 0 and t128 >= 160:
+        elif fits and t128 >= 160:
             v = 4
         else:
             v = 1 if N > 64 else 5

@@ -21,6 +21,12 @@ import torch.distributed as dist
 ALIGN = 64          # elements: keeps every view 128-byte aligned
 
 
+def _FORCE_COLLECTIVE():
+    """Rehearsal switch: issue the collective even for a world of 1 (bench.py --rehearse-dist)."""
+    import os
+    return os.environ.get("VDX_SHARD_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -98,7 +104,7 @@ class ShardedStore:
         shard = self.shards[unit]
 
         def run():
-            if self.world == 1:
+            if self.world == 1 and not _FORCE_COLLECTIVE():
                 out.copy_(shard)
             elif self._cuda:
                 dist.all_gather_into_tensor(out, shard, group=self.group)

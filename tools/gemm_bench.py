@@ -46,6 +46,15 @@ def main():
             (f"L{lvl} geglu {C}->{8 * C}", dict(mode=ops.PLAIN, cin=C, N=8 * C, geglu=True)),
             (f"L{lvl} ff2 {4 * C}->{C} +res", dict(mode=ops.PLAIN, cin=4 * C, N=C, res=True)),
         ]
+        if lvl == 0:   # transformer_in (inner width 512)
+            cases += [
+                ("Tin proj_in 320->512", dict(mode=ops.PLAIN, cin=320, N=512)),
+                ("Tin qkv 512->1536", dict(mode=ops.PLAIN, cin=512, N=1536)),
+                ("Tin out 512->512 +res", dict(mode=ops.PLAIN, cin=512, N=512, res=True)),
+                ("Tin geglu 512->4096", dict(mode=ops.PLAIN, cin=512, N=4096, geglu=True)),
+                ("Tin ff2 2048->512 +res", dict(mode=ops.PLAIN, cin=2048, N=512, res=True)),
+                ("Tin proj_out 512->320 +res", dict(mode=ops.PLAIN, cin=512, N=320, res=True)),
+            ]
         for name, c in cases:
             if only and only not in name:
                 continue
