@@ -76,11 +76,13 @@ def main():
             auto = ops.gemm_kernel_name(M, c["N"], K, c["mode"], c.get("geglu", False))
             rows.append((name, M, c["N"], K, per, flops, byts, auto))
             del a, wgt, out, res
-    print(f"{'shape':30s} {'M':>7s} {'N':>6s} {'K':>6s} | ms: {'128x128':>8s} {'256x320':>8s} {'ring4':>8s} {'128x320':>8s} | best TF/s  GB/s | auto")
+    names = ["128x128", "256x320", "ring4", "128x320"]
+    print(f"{'shape':30s} {'M':>7s} {'N':>6s} {'K':>6s} | ms: " + " ".join(f"{n:>8s}" for n in names) +
+          " | best TF/s  GB/s | auto")
     for r in rows:
         best = min(r[4])
         print(f"{r[0]:30s} {r[1]:7d} {r[2]:6d} {r[3]:6d} |     " + " ".join(f"{m:8.3f}" for m in r[4]) +
-              f" | {r[5] / best / 1e9:8.1f} {r[6] / best / 1e6:6.0f} | v{1 + r[4].index(best)} auto={r[7][:24]}")
+              f" | {r[5] / best / 1e9:8.1f} {r[6] / best / 1e6:6.0f} | {names[r[4].index(best)]} auto={r[7][:24]}")
 
 
 if __name__ == "__main__":
