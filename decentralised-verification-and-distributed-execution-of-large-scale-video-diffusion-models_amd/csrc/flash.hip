@@ -1,0 +1,275 @@
+// flash.hip — flash-style attention on v_mfma_f32_32x32x16_f16: spatial
+// self-attention (seq up to 9216, never materialised) and text cross-attention (77 keys).
+//
+// A wave owns QB sub-blocks of 32 queries (QB = 2: 64 queries per wave, 256 per 4-wave block);
+// K / V^T tiles of 64 keys go through LDS (LDS-DMA staged, double-buffered, one barrier per
+// tile) and every fragment read from LDS feeds QB MFMAs.  Per sub-block:
+//   * scores are computed TRANSPOSED, S^T = K.Q^T, so a lane owns ONE query column: the row max is
+//     lane-local plus one exchange with lane^32, and the exponentiated tile is already the B
+//     operand of O^T = V^T.P^T (accumulator-as-operand, no LDS round trip for P).  K rows are fed
+//     in the bit-swapped order that makes that operand's permuted k-index the natural key order,
+//     so V^T fragments are plain 16-byte LDS reads.  V arrives pre-transposed ([d][key]): the V
+//     projection GEMM is simply issued with swapped operands.
+//   * Q is pre-scaled by scale*log2(e); the running maximum is folded INTO the score contraction by
+//     one extra k-step ([1,0,..] row of "K" times [-m,0,..] column of "Q"), so S' = S - m costs one
+//     MFMA per 32 keys and no per-score VALU op, and in the common tile p = exp2(S') directly.
+//     m only has to be the same for a row's p and its row sum, so its fp16 rounding is harmless.
+//   * row sums by v_dot2_f32_f16 against ones.
+// The two sub-blocks are independent instruction streams inside one wave, which is what lets the
+// matrix pipe work on one while the VALU exponentiates the other (the kernel is VALU/latency
+// bound at head dim 64, not MFMA bound).
+#include "attn_common.h"
+#include <stdlib.h>
+
+struct FlashP {
+    const f16 *q, *k, *vt;
+    f16* out;
+    int ldq, ldk, ldvt, ldo;
+    int sq, skv, skv_pad, seq_per_kv;
+    float c;  // scale * log2(e)
+};
+
+template <int QB>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
+    // LDS: 2 stages x { K tile [64 key][64 d], V^T tile [64 d][64 key] }, 128-B rows,
+    // 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7)  (conflict-free for both reads)
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, seq = blockIdx.z;
+    const int kvb = seq / p.seq_per_kv;
+    const int q0 = (blockIdx.x * 4 + wave) * (32 * QB);
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane = query column, pre-scaled --------------
+    f16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qr = min(q0 + qb * 32 + r32, p.sq - 1);
+        const f16* src = p.q + ((size_t)seq * p.sq + qr) * p.ldq + head * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 raw = *(const f16x8*)(src + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (f16)((float)raw[j] * p.c);
+        }
+    }
+
+    // ---- staging by LDS-DMA (global_load_lds_dwordx4): 2 K pieces + 2 V^T pieces per wave per tile.
+    // Wave-instruction i fills LDS rows (i*256 + wave*64)/8 .. +7 of the tile; lane l lands at row
+    // +(l>>3), 16-byte slot l&7, and therefore fetches data chunk (l&7) ^ ((row>>1)&7).  Source
+    // pointers walk forward one tile per iteration; bounds are only checked in tiles that cross
+    // skv_pad (rows / chunks past it come from the zero page).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const f16* zp = (const f16*)g_zero_page;
+    const int st_row0 = tid >> 3, st_row1 = st_row0 + 32;             // K key / V^T d row of my piece 0 / 1
+    const int ch0 = (tid & 7) ^ ((st_row0 >> 1) & 7), ch1 = (tid & 7) ^ ((st_row1 >> 1) & 7);
+    const f16* kptr0 = p.k + ((size_t)kvb * p.skv_pad + st_row0) * p.ldk + head * 64 + ch0 * 8;
+    const f16* kptr1 = p.k + ((size_t)kvb * p.skv_pad + st_row1) * p.ldk + head * 64 + ch1 * 8;
+    const f16* vptr0 = p.vt + ((size_t)head * 64 + st_row0) * p.ldvt + (size_t)kvb * p.skv_pad + ch0 * 8;
+    const f16* vptr1 = p.vt + ((size_t)head * 64 + st_row1) * p.ldvt + (size_t)kvb * p.skv_pad + ch1 * 8;
+    const size_t kstep = (size_t)64 * p.ldk;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue = [&](int t, int buf) {
+        char* sk = smem + buf * 16384 + wv * 1024;
+        const int k0 = t * 64;
+        const f16 *k0p = kptr0, *k1p = kptr1, *v0p = vptr0, *v1p = vptr1;
+        if (k0 + 64 > p.skv_pad) {                                    // tile crosses skv_pad (wave-uniform)
+            if (k0 + st_row0 >= p.skv_pad) k0p = zp;
+            if (k0 + st_row1 >= p.skv_pad) k1p = zp;
+            if (k0 + ch0 * 8 >= p.skv_pad) v0p = zp;                  // chunks never straddle skv_pad
+            if (k0 + ch1 * 8 >= p.skv_pad) v1p = zp;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)k0p, (lptr_t)sk, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)k1p, (lptr_t)(sk + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)v0p, (lptr_t)(sk + 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)v1p, (lptr_t)(sk + 8192 + 4096), 16, 0, 0);
+        kptr0 += kstep;
+        kptr1 += kstep;
+        vptr0 += 64;
+        vptr1 += 64;
+    };
+
+    f32x16 o_acc[QB][2];
+    float m_run[QB], l_run[QB];            // offset in use (exp2 units, fp16-representable); my half of the row sum
+    f16x8 negm[QB], e0;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = l_run[qb] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o_acc[qb][0][j] = o_acc[qb][1][j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) negm[qb][j] = (f16)0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e0[j] = (f16)((j == 0 && h == 0) ? 1.0f : 0.0f);
+    f16x2 one2;
+    one2[0] = one2[1] = (f16)1.0f;
+
+    const int krow = pi_row(r32);
+    const int ntiles = (p.skv + 63) >> 6;
+    issue(0, 0);
+    __syncthreads();                       // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) issue(t + 1, cur ^ 1);   // buffer cur^1 was last read before the previous barrier
+        const char* Ks = smem + cur * 16384;
+        const char* Vs = Ks + 8192;
+        const int k0 = t * 64;
+
+        // ---- S' = K . Q^T - m : two 32-key blocks, each K fragment feeds QB sub-blocks ------------
+        f32x16 s_acc[QB][2], zero16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) zero16[j] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int row = kb * 32 + krow;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + h;
+                const f16x8 kf = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], ks == 0 ? zero16 : s_acc[qb][kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, negm[qb], s_acc[qb][kb], 0, 0, 0);   // - m
+        }
+        if (k0 + 64 > p.skv) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (k0 + kb * 32 + acc_key(j, h) >= p.skv) s_acc[qb][kb][j] = NEG_BIG;
+        }
+        // ---- row maxima; the offset moves only when a maximum grows by more than 1/16 (p stays
+        // <= 2^(1/16): no overflow, no perpetual re-trigger); tile 0 establishes it ----------------
+        float mx[QB];
+        bool move[QB], any_move = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float m = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) m = fmaxf(m, s_acc[qb][kb][j]);
+            mx[qb] = fmaxf(m, __shfl_xor(m, 32, 64));
+            move[qb] = t == 0 || mx[qb] > 0.0625f;
+            any_move |= move[qb];
+        }
+        if (__builtin_amdgcn_ballot_w64(any_move) != 0) {            // rare after the first tiles
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float m_new = (float)(f16)(m_run[qb] + (move[qb] ? mx[qb] : 0.f));
+                const float d = m_new - m_run[qb];                   // shift actually applied
+                m_run[qb] = m_new;
+                negm[qb][0] = (f16)(h == 0 ? -m_new : 0.f);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) s_acc[qb][kb][j] -= d;
+                if (t > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    l_run[qb] *= alpha;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        o_acc[qb][0][j] *= alpha;
+                        o_acc[qb][1][j] *= alpha;
+                    }
+                }
+            }
+        }
+        // ---- p = exp2(S') packed to fp16 pairs, row sums by dot2; O^T += V^T . P^T ------------------
+        f16x8 pf[QB][4];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    f16x2 pp;
+                    pp[0] = (f16)__builtin_amdgcn_exp2f(s_acc[qb][kb][j]);
+                    pp[1] = (f16)__builtin_amdgcn_exp2f(s_acc[qb][kb][j + 1]);
+                    l_run[qb] = __builtin_amdgcn_fdot2(pp, one2, l_run[qb], false);
+                    pf[qb][kb * 2 + (j >> 3)][j & 7] = pp[0];
+                    pf[qb][kb * 2 + (j >> 3)][(j & 7) + 1] = pp[1];
+                }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {  // kk = 2*kb + s : keys 16*kk + 8*h .. +7
+            const int c = 2 * kk + h;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + r32;
+                const f16x8 vf = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kk], o_acc[qb][db], 0, 0, 0);
+            }
+        }
+        __syncthreads();                   // next tile landed (vmcnt(0)) and this one is fully read
+    }
+
+    // ---- epilogue: O[query][d], lane = query; pair lanes (l, l^32) to emit 16-byte stores ----
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float inv = 1.0f / (l_run[qb] + __shfl_xor(l_run[qb], 32, 64));
+        const int qrow = q0 + qb * 32 + r32;
+        f16* dst = p.out + ((size_t)seq * p.sq + qrow) * p.ldo + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                // register group g holds d = 32*db + 8*g + 4*h + (0..3)
+                f16x4 mine[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mine[u][j] = (f16)(o_acc[qb][db][4 * (g + u) + j] * inv);
+                const f16x4 send = h ? mine[0] : mine[1];
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 sb = __builtin_bit_cast(u32x2, send), rb;
+                rb[0] = __shfl_xor(sb[0], 32, 64);
+                rb[1] = __shfl_xor(sb[1], 32, 64);
+                const f16x4 recv = __builtin_bit_cast(f16x4, rb);
+                f16x8 o;
+                const f16x4 lo = h ? recv : mine[0], hi = h ? mine[1] : recv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = lo[j];
+                    o[4 + j] = hi[j];
+                }
+                if (qrow < p.sq) *(f16x8*)(dst + 32 * db + 8 * (g + h)) = o;
+            }
+        }
+    }
+}
+
+extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                  void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
+                                  int seq_per_kv, float scale, vdx_stream_t stream) {
+    VDX_CHECK(q && k && vt && out, "flash_attn: null pointer");
+    VDX_CHECK(n_seq > 0 && sq > 0 && skv > 0 && heads > 0 && seq_per_kv > 0, "flash_attn: empty problem");
+    VDX_CHECK(skv_pad >= skv && skv_pad % 8 == 0, "flash_attn: skv_pad=%d must be >= skv=%d and a multiple of 8", skv_pad, skv);
+    VDX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0, "flash_attn: leading dims must be multiples of 8");
+    VDX_CHECK(n_seq % seq_per_kv == 0, "flash_attn: n_seq=%d not a multiple of seq_per_kv=%d", n_seq, seq_per_kv);
+    VDX_CHECK(heads <= 65535 && n_seq <= 65535, "flash_attn: grid too large");
+    FlashP p;
+    p.q = (const f16*)q; p.k = (const f16*)k; p.vt = (const f16*)vt; p.out = (f16*)out;
+    p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+    p.sq = sq; p.skv = skv; p.skv_pad = skv_pad; p.seq_per_kv = seq_per_kv;
+    p.c = scale * 1.44269504088896341f;
+    static const int force_qb = getenv("VDX_FLASH_QB") ? atoi(getenv("VDX_FLASH_QB")) : 0;   // tuning knob
+    // 64 queries per wave when the sequence is long enough to fill the chip with 256-query blocks
+    const bool two = force_qb ? force_qb == 2 : (sq >= 512 && skv >= 256);
+    if (two) {
+        dim3 grid((sq + 255) / 256, heads, n_seq);
+        hipLaunchKernelGGL(flash_attn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        dim3 grid((sq + 127) / 128, heads, n_seq);
+        hipLaunchKernelGGL(flash_attn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
+    return vdx_launch_status("vdx_flash_attn_f16");
+}
