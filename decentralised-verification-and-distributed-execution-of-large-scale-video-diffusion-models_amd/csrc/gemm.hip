@@ -123,8 +123,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * NT * 16), 16, 0, 0);
             }
         }
-        kc += 64;
-        if (kc == ct) { kc = 0; ++tap; }
+        // K order of the gathers is (64-channel slice, tap, channel): all taps of one channel slice are
+        // consumed back to back, so the shifted re-reads of the same source pixels hit the XCD's L2
+        // (tap-major order streamed ~0.5 MB per CU between re-uses and thrashed it: 7.5x re-fetch).
+        if (MODE == 0) {
+            kc += 64;
+        } else if (++tap == (MODE == 1 ? 9 : 3)) {
+            tap = 0;
+            kc += 64;
+        }
     };
 
     f32x4 acc[TM][TN];

@@ -128,8 +128,17 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * NW * 1024), 16, 0, 0);
             }
         }
-        kc += 32;
-        if (kc == ct) { kc = 0; ++tap; }
+        // K order of the gathers: (64-channel slice, tap, channel) as in gemm.hip; a K-step covers
+        // half a slice, so the half index toggles fastest.
+        if (MODE == 0) {
+            kc += 32;
+        } else {
+            kc ^= 32;
+            if ((kc & 32) == 0 && ++tap == (MODE == 1 ? 9 : 3)) {
+                tap = 0;
+                kc += 64;
+            }
+        }
     };
 
     f32x4 acc[TM][TN];

@@ -22,17 +22,26 @@ def pad_rows(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
     return out
 
 
+def _taps_slice_major(w_taps: torch.Tensor) -> torch.Tensor:
+    """[Cout][T][Cin] -> [Cout][T*Cin] in the kernels' K order (64-channel slice, tap, channel):
+    K = (c // 64) * T * 64 + tap * 64 + c % 64.  All taps of one channel slice are consumed back to
+    back, which keeps the shifted re-reads of the source pixels in L2 (gemm.hip)."""
+    co, t, ci = w_taps.shape
+    assert ci % 64 == 0, "gathered convolutions need Cin % 64 == 0"
+    return w_taps.reshape(co, t, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, t * ci).contiguous()
+
+
 def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
-    """Conv2d weight [Cout][Cin][3][3] -> [Cout][9*Cin] with K = (ky*3+kx)*Cin + c."""
+    """Conv2d weight [Cout][Cin][3][3] -> [Cout][9*Cin], tap = ky*3+kx, K order of `_taps_slice_major`."""
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
-    return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    return _taps_slice_major(w.permute(0, 2, 3, 1).reshape(co, 9, ci))
 
 
 def pack_conv_in(w: torch.Tensor) -> torch.Tensor:
     """conv_in weight [Cout][Cin][3][3] -> [Cout][Kpad]: K = (ky*3+kx)*Cin + c zero-padded to a
     multiple of 64 (matches the im2col rows of vdx_im2col_in_f16)."""
-    p = pack_conv3x3(w)
+    p = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)          # plain (tap, channel) order: plain GEMM
     k = p.shape[1]
     out = p.new_zeros((p.shape[0], round_up(k, 64)))
     out[:, :k] = p
@@ -45,9 +54,9 @@ def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_tconv3(w: torch.Tensor) -> torch.Tensor:
-    """Conv3d weight [Cout][Cin][3][1][1] -> [Cout][3*Cin] with K = kt*Cin + c."""
+    """Conv3d weight [Cout][Cin][3][1][1] -> [Cout][3*Cin], tap = kt, K order of `_taps_slice_major`."""
     co, ci = w.shape[:2]
-    return w.reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).contiguous()
+    return _taps_slice_major(w.reshape(co, ci, 3).permute(0, 2, 1))
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor):

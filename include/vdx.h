@@ -46,7 +46,8 @@ enum { VDX_EPI_GEGLU = 1 };
 typedef struct vdx_gemm_args {
     const void* a;        /* fp16 source 0, row stride lda (elements)                           */
     const void* a2;       /* fp16 source 1 (channel concat after source 0) or NULL              */
-    const void* w;        /* fp16 [N][K], K contiguous; conv: K = tap*Ct + c, tap = ky*3+kx      */
+    const void* w;        /* fp16 [N][K], K contiguous; gathers: K = (c/64)*T*64 + tap*64 + c%64,
+                             T = 9 (tap = ky*3+kx) or 3 (tap = kt)                                 */
     const void* bias;     /* fp16 [N] or NULL                                                    */
     const void* bias2;    /* fp16 [M / rows_per_bias2][N] or NULL (time-embedding projection)    */
     const void* residual; /* fp16 [M][ldr] or NULL, added after bias                             */

@@ -90,12 +90,16 @@ def test_scheduler_step_has_no_cpu_path():
 
 
 def test_packing_layouts():
-    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    # gathered convolutions: K = (c // 64) * T * 64 + tap * 64 + c % 64
+    w = torch.arange(2 * 128 * 9, dtype=torch.float32).reshape(2, 128, 3, 3)
     p = packing.pack_conv3x3(w)
-    assert p.shape == (2, 27) and p[1, (1 * 3 + 2) * 3 + 1] == w[1, 1, 1, 2]
-    w3 = torch.arange(2 * 4 * 3, dtype=torch.float32).reshape(2, 4, 3, 1, 1)
+    c, ky, kx = 70, 1, 2
+    assert p.shape == (2, 9 * 128) and p[1, (c // 64) * 9 * 64 + (ky * 3 + kx) * 64 + c % 64] == w[1, c, ky, kx]
+    w3 = torch.arange(2 * 128 * 3, dtype=torch.float32).reshape(2, 128, 3, 1, 1)
     p = packing.pack_tconv3(w3)
-    assert p.shape == (2, 12) and p[1, 2 * 4 + 3] == w3[1, 3, 2, 0, 0]
+    assert p.shape == (2, 3 * 128) and p[1, (c // 64) * 3 * 64 + 2 * 64 + c % 64] == w3[1, c, 2, 0, 0]
+    wi = torch.arange(2 * 4 * 9, dtype=torch.float32).reshape(2, 4, 3, 3)
+    assert packing.pack_conv_in(wi)[1, (1 * 3 + 2) * 4 + 3] == wi[1, 3, 1, 2]
     w = torch.arange(16 * 2, dtype=torch.float32).reshape(16, 2)
     b = torch.arange(16, dtype=torch.float32)
     wp, bp = packing.pack_geglu(w, b)
