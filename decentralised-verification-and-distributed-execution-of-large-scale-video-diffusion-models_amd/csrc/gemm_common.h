@@ -15,50 +15,72 @@ struct GemmP {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// ---- epilogue shared by both kernels: lane holds rows mb + 16i + frow, and per accumulator pair
-// (2a, 2a+1) the 8 consecutive columns nb + 32a + 8*fq .. +7 --------------------------------------
+// ---- epilogue shared by the kernels: lane holds rows mb + 16i + frow, and per accumulator pair
+// (2a, 2a+1) the 8 consecutive columns nb + 32a + 8*fq .. +7.
+// All side inputs of one row group (bias, time-embedding row, residual) are requested TOGETHER and
+// waited for once: issued one by one next to their use, each load was a full serialized memory
+// round trip (20 per lane per tile), which is what the short-K layers' time went to.
 template <int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TM][TN], int mb, int nb, int frow, int fq) {
+    constexpr int NA = TN / 2;
+    const f16* zp = (const f16*)g_zero_page;
+    // per-column bias: the same for every row group -> loaded once
+    f16x8 bv[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[a][j] = (f16)0.f;
+    if (p.bias) {                                   // absent inputs cost nothing (uniform branches)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int n = nb + a * 32 + fq * 8;
+            bv[a] = *(const f16x8*)(n < p.N ? p.bias + n : zp);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = mb + i * 16 + frow;
-        if (m >= p.M) continue;
-        const f16* b2row = p.bias2 ? p.bias2 + (size_t)(m / p.rpb2) * p.ldb2 : nullptr;
+        const bool row_ok = m < p.M;
+        f16x8 rv[NA], b2v[NA];
 #pragma unroll
-        for (int a = 0; a < TN / 2; ++a) {
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv[a][j] = b2v[a][j] = (f16)0.f;
+        if (!GEGLU && p.res) {
+            const f16* rrow = p.res + (size_t)(row_ok ? m : 0) * p.ldr;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int n = nb + a * 32 + fq * 8;
+                rv[a] = *(const f16x8*)((row_ok && n < p.N) ? rrow + n : zp);
+            }
+        }
+        if (!GEGLU && p.bias2) {
+            const f16* b2row = p.bias2 + (size_t)((row_ok ? m : 0) / p.rpb2) * p.ldb2;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int n = nb + a * 32 + fq * 8;
+                b2v[a] = *(const f16x8*)((row_ok && n < p.N) ? b2row + n : zp);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
             const int n = nb + a * 32 + fq * 8;
-            if (n >= p.N) continue;
             float v[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = acc[i][2 * a][j];
-                v[4 + j] = acc[i][2 * a + 1][j];
-            }
-            if (p.bias) {
-                const f16x8 b = *(const f16x8*)(p.bias + n);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
+                v[j] = acc[i][2 * a][j] + (float)bv[a][j];
+                v[4 + j] = acc[i][2 * a + 1][j] + (float)bv[a][4 + j];
             }
             if (GEGLU) {
                 f16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (f16)(v[j] * gelu_erf_f(v[4 + j]));
-                *(f16x4*)(p.out + (size_t)m * p.ldo + (n >> 1)) = o;
+                if (row_ok && n < p.N) *(f16x4*)(p.out + (size_t)m * p.ldo + (n >> 1)) = o;
             } else {
-                if (b2row) {
-                    const f16x8 b = *(const f16x8*)(b2row + n);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
-                }
-                if (p.res) {
-                    const f16x8 r = *(const f16x8*)(p.res + (size_t)m * p.ldr + n);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
-                }
                 f16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-                *(f16x8*)(p.out + (size_t)m * p.ldo + n) = o;
+                for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] + (float)b2v[a][j] + (float)rv[a][j]);
+                if (row_ok && n < p.N) *(f16x8*)(p.out + (size_t)m * p.ldo + n) = o;
             }
         }
     }
