@@ -261,6 +261,37 @@ def test_flash_attention_large_scores_online_rescale(gpu):
     close(out, ref, tol=4e-3)
 
 
+@pytest.mark.parametrize("case", ["all_very_negative", "all_very_positive", "late_spike_up", "drift_down_then_up"])
+@pytest.mark.parametrize("s", [320, 640])
+def test_flash_attention_lazy_offset_branches(gpu, case, s):
+    """The softmax offset is lazy (kept at 0 while row maxima of the scaled scores stay in (-4, 10]).
+    These inputs FORCE every branch of that logic — rows that start far below the window, far above
+    it, jump late, or drift — on both the 32- and 64-queries-per-wave kernels (s = 320 / 640); a full
+    fp32 reference checks every output element (a rescale bug is silent: no NaN)."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(len(case) + s)
+    q = h(torch.randn(s, 64, generator=g))
+    k = h(torch.randn(s, 64, generator=g))
+    v = h(torch.randn(s, 64, generator=g))
+    u = q.mean(0) / q.mean(0).norm()
+    if case == "all_very_negative":
+        q = h(q + 6 * u)
+        k = h(k - 6 * u)                       # every score ~ -36*... strongly negative
+    elif case == "all_very_positive":
+        q = h(q + 9 * u)
+        k = h(k + 9 * u)                       # scaled scores ~ +14: above the window from tile 0
+    elif case == "late_spike_up":
+        k[s - 20] = h(q.mean(0) * 40 + 3)      # one key far above the window in the last tile
+    else:
+        ramp = torch.linspace(-8, 8, s)[:, None]
+        q = h(q + 4 * u)
+        k = h(k + ramp * u)                    # maxima drift from below the window to above it
+    ref = _attn_ref(q[None], k[None], v[None], 1)
+    out = ops.flash_attn(q.half().to(gpu), k.half().to(gpu), v.t().contiguous().half().to(gpu), n_seq=1, sq=s,
+                         skv=s, skv_pad=s, heads=1, seq_per_kv=1, scale=0.125)
+    close(out, ref, tol=4e-3)
+
+
 @pytest.mark.parametrize("B,Fr,s,heads,skv", [(2, 3, 144, 2, 77), (1, 4, 64, 1, 77), (2, 2, 100, 2, 5)])
 def test_flash_cross_attention(gpu, B, Fr, s, heads, skv):
     ops, _ = _ops()
