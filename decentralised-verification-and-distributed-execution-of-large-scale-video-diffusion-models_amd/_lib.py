@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdx_hip.so")
+LIB_PATH = os.environ.get("VDX_LIB_PATH") or os.path.join(_HERE, "libvdx_hip.so")   # override: dev/diagnostic builds
 
 
 class GemmArgs(C.Structure):

@@ -21,136 +21,185 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 
-template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int ACH = BM * 8 / NT, BCH = BN * 8 / NT;
-    constexpr int STAGE = (BM + BN) * 128;
-    static_assert(TN % 2 == 0 && ACH >= 1 && BCH >= 1 && NT % 8 == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VDX_STAMPS   // diagnostic build only (make stamps): per-block phase clocks, never in the product library
+#define STAMP_MAX 32768
+static __device__ unsigned long long g_stamps[STAMP_MAX * 8];
+extern "C" int vdx_debug_read_stamps(void* dst, int nblocks) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t)nblocks * 64) == hipSuccess ? 0 : -1;
+}
+#define STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i)
+#endif
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+// ---- staging of one output tile's K tiles (LDS-DMA) -------------------------------------------
+// Issue slot `it` (of IT per operand) fills, with its DMA instruction i, 16-byte slot it&7 of physical LDS
+// row prow + i*RPP.  Slot s of physical row r must hold data chunk s ^ (r & 7); RPP is a multiple of 8, so
+// the chunk is the same for every i.  Rows past M (and weight rows past N) are CLAMPED to the last valid
+// row: their products land in accumulators the epilogue never stores.
+//
+// SPLIT (8-wave blocks): waves 0-3 stage the activation rows, waves 4-7 the weight rows, 256 issue slots
+// each.  Waves w and w+4 share a SIMD; a DMA instruction costs its wave ~60-100 issue cycles, and with
+// all eight waves issuing their share at the top of a K tile the matrix pipe sat idle for that long in
+// every K tile (measured: DMA-only 1.0 us and MFMA-only 1.65 us per K tile, together 2.1 us).  Now the
+// activation waves issue at the top while their partners run MFMAs, and the weight waves issue between
+// their two K halves while the activation waves run MFMAs.  The weights are L2-resident (0.2-0.4 us to
+// land), so half a K tile of lead is enough for them; the activation rows, which may come from HBM, keep
+// the full K tile of lead.
+template <int BM, int BN, int NT, int MODE, bool SPLIT>
+struct Stager {
+    static constexpr int IT = SPLIT ? NT / 2 : NT;        // issue slots per operand
+    static constexpr int RPP = IT / 8;                    // LDS rows covered by one DMA instruction of all slots
+    static constexpr int ACH = BM / RPP, BCH = BN / RPP;  // DMA instructions per slot and K tile: A rows, W rows
+    static constexpr int STAGE = (BM + BN) * 128;
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && RPP % 32 == 0, "tile shape");
+    static_assert(!SPLIT || NT == 512, "SPLIT pairs wave w with wave w+4");
+    int d0[ACH], d1[ACH];   // MODE 0: source row | MODE 1: image base row, (y+1)<<16|(x+1) | MODE 2: row, frame
+    int wrow0, csw, iwave;
+    int tap, kc, kw;        // the NEXT K tile to be issued (kw = its first weight column)
 
-    // ---- per-thread staging descriptors (fixed across K tiles) ------------------------------
-    // DMA instruction i of this wave fills LDS rows (i*NT + wave*64)/8 .. +7; lane l lands at row
-    // +(l>>3), 16-byte slot l&7.  Slot s of physical row r must hold data chunk s ^ (r & 7).
-    const int prow = tid >> 3;                         // physical row of chunk 0 (chunk i: + i*NT/8)
-    const int csw = ((tid & 7) ^ (prow & 7)) * 8;      // element offset of the data chunk this lane fetches
-    size_t a_off[ACH];                    // MODE 0: row offset in source 0;  MODE 1/2: see below
-    size_t a_off2[ACH];                   // MODE 0: row offset in source 1
-    int a_y[ACH], a_x[ACH];               // MODE 1: top-left tap coords;  MODE 2: a_y = frame idx
-    bool a_ok[ACH];
+    __device__ __forceinline__ void setup(const GemmP& p, int tid, int m0, int n0) {
+        const int it = SPLIT ? (tid & (IT - 1)) : tid;
+        const int prow = it >> 3;
+        iwave = __builtin_amdgcn_readfirstlane(it >> 6);
+        csw = ((it & 7) ^ (prow & 7)) * 8;    // element offset of the data chunk this slot fetches
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-        const int m = m0 + prow + i * (NT / 8);
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        if (MODE == 0) {
-            a_off[i] = (size_t)mm * p.lda;
-            a_off2[i] = (size_t)mm * p.lda2;
-            a_y[i] = a_x[i] = 0;
-        } else if (MODE == 1) {
-            const int per = p.h_out * p.w_out;
-            const int n = mm / per, rem = mm - n * per;
-            const int yo = rem / p.w_out, xo = rem - yo * p.w_out;
-            a_y[i] = yo * p.stride - 1;
-            a_x[i] = xo * p.stride - 1;
-            a_off[i] = (size_t)n * p.h_in * p.w_in;   // first source row of this image
-            a_off2[i] = 0;
-        } else {
-            a_y[i] = (mm / p.hw) % p.frames;
-            a_x[i] = 0;
-            a_off[i] = (size_t)mm;
-            a_off2[i] = 0;
+        for (int i = 0; i < ACH; ++i) {
+            const int mm = min(m0 + prow + i * RPP, p.M - 1);
+            if (MODE == 0) {
+                d0[i] = mm;
+                d1[i] = 0;
+            } else if (MODE == 1) {
+                const int per = p.h_out * p.w_out;
+                const int n = mm / per, rem = mm - n * per;
+                const int yo = rem / p.w_out, xo = rem - yo * p.w_out;
+                d0[i] = n * p.h_in * p.w_in;
+                d1[i] = ((yo * p.stride) << 16) | (xo * p.stride);
+            } else {
+                d0[i] = mm;
+                d1[i] = (mm / p.hw) % p.frames;
+            }
         }
+        // Physical LDS row pr holds weight row 8q+4b+j where pr = 16b+4q+j inside each 32-row group, so
+        // that after the MFMA a lane owns 8 consecutive output columns (RPP % 32 == 0: same for every i).
+        wrow0 = n0 + ((((prow >> 2) & 3) << 3) | (((prow >> 4) & 1) << 2) | (prow & 3)) + (prow & ~31);
+        tap = kc = kw = 0;
     }
-    const f16* zp = (const f16*)g_zero_page;
-    const f16* b_src[BCH];                // weight row base (+ data chunk) or the zero page (N tail)
-    int b_step[BCH];                      // elements to advance per K tile (0 for the zero page)
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-        // Physical LDS row pr holds weight row 8q+4b+j where pr = 16b+4q+j inside each 32-row group,
-        // so that after the MFMA a lane owns 8 consecutive output columns.
-        const int pr = prow + i * (NT / 8);
-        const int r = (pr & ~31) | (((pr >> 2) & 3) << 3) | (((pr >> 4) & 1) << 2) | (pr & 3);
-        const bool ok = n0 + r < p.N;
-        b_src[i] = ok ? p.w + (size_t)(n0 + r) * p.K + csw : zp;
-        b_step[i] = ok ? 64 : 0;
-    }
-
-    // ---- K-tile walker: issue the LDS-DMA of one tile ---------------------------------------
-    const int ct = p.c1 + p.c2;           // channels per tap
-    int tap = 0, kc = 0;                  // state of the NEXT tile to be issued
-    auto issue = [&](int buf) {
-        char* sa = smem + buf * STAGE + wave * 1024;
-        char* sb = sa + BM * 128;
+    // weight rows of the next K tile -> stage buffer `buf`
+    __device__ __forceinline__ void issue_w(const GemmP& p, char* smem, int buf) {
+        char* sb = smem + buf * STAGE + BM * 128 + iwave * 1024;
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)b_src[i], (lptr_t)(sb + i * NT * 16), 16, 0, 0);
-            b_src[i] += b_step[i];
+            const int r = min(wrow0 + i * RPP, p.N - 1);
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.w + (size_t)r * p.K + kw + csw), (lptr_t)(sb + i * RPP * 128), 16, 0, 0);
         }
+    }
+    // (gathered) activation rows of the next K tile -> stage buffer `buf`
+    __device__ __forceinline__ void issue_a(const GemmP& p, char* smem, int buf) {
+        const f16* zp = (const f16*)g_zero_page;
+        char* sa = smem + buf * STAGE + iwave * 1024;
         if (MODE == 0) {
             const bool first = kc < p.c1;
+            const f16* base = first ? p.a + kc + csw : p.a2 + (kc - p.c1) + csw;
+            const int ld = first ? p.lda : p.lda2;
 #pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                const f16* src = first ? p.a + a_off[i] + kc : p.a2 + a_off2[i] + (kc - p.c1);
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_ok[i] ? src + csw : zp), (lptr_t)(sa + i * NT * 16), 16, 0, 0);
-            }
+            for (int i = 0; i < ACH; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)d0[i] * ld), (lptr_t)(sa + i * RPP * 128), 16, 0, 0);
         } else if (MODE == 1) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int hlim = p.h_in << p.ups, wlim = p.w_in << p.ups;
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
-                int y = a_y[i] + ky, x = a_x[i] + kx;
-                const bool ok = a_ok[i] && (unsigned)y < (unsigned)hlim && (unsigned)x < (unsigned)wlim;
+                int y = (d1[i] >> 16) + ky - 1, x = (d1[i] & 0xffff) + kx - 1;
+                const bool ok = (unsigned)y < (unsigned)hlim && (unsigned)x < (unsigned)wlim;
                 y >>= p.ups;
                 x >>= p.ups;
-                const f16* src = p.a + (a_off[i] + (size_t)(y * p.w_in + x)) * p.lda + kc + csw;
-                __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * NT * 16), 16, 0, 0);
+                const f16* src = p.a + (size_t)(d0[i] + y * p.w_in + x) * p.lda + kc + csw;
+                __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * RPP * 128), 16, 0, 0);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
-                const int f = a_y[i] + tap - 1;
-                const bool ok = a_ok[i] && (unsigned)f < (unsigned)p.frames;
-                const f16* src = p.a + (a_off[i] + (size_t)((tap - 1) * p.hw)) * p.lda + kc + csw;
-                __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * NT * 16), 16, 0, 0);
+                const int f = d1[i] + tap - 1;
+                const bool ok = (unsigned)f < (unsigned)p.frames;
+                const f16* src = p.a + (size_t)(d0[i] + (tap - 1) * p.hw) * p.lda + kc + csw;
+                __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * RPP * 128), 16, 0, 0);
             }
         }
+    }
+    __device__ __forceinline__ void advance() {
         // K order of the gathers is (64-channel slice, tap, channel): all taps of one channel slice are
         // consumed back to back, so the shifted re-reads of the same source pixels hit the XCD's L2
         // (tap-major order streamed ~0.5 MB per CU between re-uses and thrashed it: 7.5x re-fetch).
+        kw += 64;
         if (MODE == 0) {
             kc += 64;
         } else if (++tap == (MODE == 1 ? 9 : 3)) {
             tap = 0;
             kc += 64;
         }
-    };
+    }
+};
+
+template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    typedef Stager<BM, BN, NT, MODE, SPLIT> Stage;
+    constexpr int STAGE = Stage::STAGE;
+    static_assert(TN % 2 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef VDX_STAMPS
+    unsigned long long st_[4];
+    const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime();
+    STAMP(0);
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nk = p.K >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+    const bool does_a = !SPLIT || wave < 4, does_w = !SPLIT || wave >= 4;
+
+    Stage sg;
+    sg.setup(p, tid, m0, n0);
+    if (does_w) sg.issue_w(p, smem, 0);
+    if (does_a) sg.issue_a(p, smem, 0);
+    sg.advance();
 
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K >> 6;
-    const int frow = lane & 15, fq = lane >> 4;
-    issue(0);
     __syncthreads();                      // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
+    STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) issue(cur ^ 1);  // buffer cur^1 was last read before the previous barrier
+        const bool more = kt + 1 < nk;
+#if !(defined(VDX_STAMPS) && VDX_ABL == 2)   // diagnostic ablation 2: no DMA inside the K loop
+        // buffer cur^1 was last read before the previous barrier
+#if !(defined(VDX_STAMPS) && VDX_ABL == 5)    // ablation 5: no activation DMA in the loop
+        if (more && does_a) sg.issue_a(p, smem, cur ^ 1);
+#endif
+#if !(defined(VDX_STAMPS) && VDX_ABL == 6)    // ablation 6: no weight DMA in the loop
+        if (more && !SPLIT) sg.issue_w(p, smem, cur ^ 1);
+#endif
+#endif
         const char* As = smem + cur * STAGE;
         const char* Bs = As + BM * 128;
+#if defined(VDX_STAMPS) && VDX_ABL == 1         // diagnostic ablation 1: DMA only, no LDS reads / MFMA
+        if (false)
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+#if !(defined(VDX_STAMPS) && (VDX_ABL == 2 || VDX_ABL == 6))
+            if (SPLIT && ks == 1 && more && does_w) sg.issue_w(p, smem, cur ^ 1);
+#endif
             f16x8 af[TM];
             const int c = ks * 4 + fq;
 #pragma unroll
@@ -176,17 +225,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
                             __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][g * GS + j], 0, 0, 0);
             }
         }
-        __syncthreads();                  // next tile landed (vmcnt(0)) and this one is fully read
+        if (more) sg.advance();
+        __syncthreads();                  // next K tile landed (vmcnt(0)) and this one is fully read
     }
 
+    STAMP(2);
     gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * WTM, n0 + wn * WTN, frow, fq);
+#ifdef VDX_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);        // stores drained
+    STAMP(3);
+    if (tid == 0 && blockIdx.x < STAMP_MAX) {
+        unsigned long long* d = g_stamps + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 4; ++i) d[i] = st_[i];
+        d[4] = r0_;
+        d[5] = __builtin_amdgcn_s_memrealtime();
+        d[6] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        d[7] = (unsigned long long)bid;
+    }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT = false>
 static int launch(const GemmP& p, hipStream_t st) {
     constexpr int lds = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<BM, BN, WM, WN, MODE, GEGLU>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, MODE, GEGLU, SPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -202,7 +266,8 @@ static int launch(const GemmP& p, hipStream_t st) {
 
 // Kernel choice.  `force` (vdx_gemm_args.epilogue bits 8..11, a testing/tuning knob) pins a
 // variant: 1 = 128x128 two-stage, 2 = 256x320 two-stage (K-step 64), 3 = 256x320 four-stage ring
-// (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 5 = 256x64.
+// (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 5 = 256x64, 6 = variant 2 without the
+// split staging roles (every wave issues its share of both operands at the top of the K tile).
 template <int MODE, bool GEGLU>
 static int pick_tile(const GemmP& p, int force, hipStream_t st) {
     int v = force;
@@ -224,7 +289,8 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
     }
     switch (v) {
         case 1: return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
-        case 2: return launch<256, 320, 4, 2, MODE, GEGLU>(p, st);
+        case 2: return launch<256, 320, 4, 2, MODE, GEGLU, MODE != 0>(p, st);   // split roles pay on the gathers only
+        case 6: return launch<256, 320, 4, 2, MODE, GEGLU, false>(p, st);
         case 3: return vdx_gemm_ring_launch(p, MODE, GEGLU, 0, st);
         case 4: return vdx_gemm_ring_launch(p, MODE, GEGLU, 1, st);
         case 5: return launch<256, 64, 4, 1, MODE, GEGLU>(p, st);

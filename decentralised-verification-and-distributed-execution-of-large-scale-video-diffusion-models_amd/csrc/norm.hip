@@ -7,13 +7,19 @@
 // (coalesced 16-byte accesses, per-channel scale/shift held in registers).
 #include "vdx_common.h"
 
-#define GN_ROWS 128  // rows of one sample per block
+// Rows of one sample per block: 128 for the big levels; halved until the grid has >= 1024 blocks so the
+// deep levels (6912 rows in all at level 3) still spread over the 256 CUs instead of ~50-100 blocks.
+static int gn_slab_rows(int n_samples, int rows_per_sample) {
+    int rows = 128;
+    while (rows > 8 && (long long)n_samples * ((rows_per_sample + rows - 1) / rows) < 1024) rows >>= 1;
+    return rows;
+}
 
 struct GnP {
     const f16 *x, *x2;
     int c1, c2, ldx, ldx2;
     int C, G, cpg, nvec, krows;      // nvec = C/8, krows = rows processed in parallel per block
-    int n_samples, rps, nslabs;      // rps = rows per sample
+    int n_samples, rps, nslabs, slab_rows;   // rps = rows per sample
     float* partial;                  // [n_samples][nslabs][G][2]  (sum, sumsq)
     float* ab;                       // [n_samples][C][2]          (scale, shift)
 };
@@ -34,8 +40,8 @@ __global__ void gn_partial_kernel(const GnP p) {
     float s[8], ss[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
-    const int r_end = min(p.rps, (slab + 1) * GN_ROWS);
-    for (int r = slab * GN_ROWS + rsub; r < r_end; r += p.krows) {
+    const int r_end = min(p.rps, (slab + 1) * p.slab_rows);
+    for (int r = slab * p.slab_rows + rsub; r < r_end; r += p.krows) {
         const f16x8 v = gn_load(p, (size_t)sample * p.rps + r, cv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -105,8 +111,8 @@ __global__ void gn_apply_kernel(const GnP p, f16* y, int ldy) {
         a[j] = ab[2 * j];
         b[j] = ab[2 * j + 1];
     }
-    const int r_end = min(p.rps, (slab + 1) * GN_ROWS);
-    for (int r = slab * GN_ROWS + rsub; r < r_end; r += p.krows) {
+    const int r_end = min(p.rps, (slab + 1) * p.slab_rows);
+    for (int r = slab * p.slab_rows + rsub; r < r_end; r += p.krows) {
         const size_t row = (size_t)sample * p.rps + r;
         const f16x8 v = gn_load(p, row, cv);
         f16x8 o;
@@ -127,7 +133,8 @@ static int gn_threads(int nvec, int* krows) {
 }
 
 extern "C" size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G) {
-    const size_t nslabs = (rows_per_sample + GN_ROWS - 1) / GN_ROWS;
+    const int rows = gn_slab_rows(n_samples, rows_per_sample);
+    const size_t nslabs = (rows_per_sample + rows - 1) / rows;
     return ((size_t)n_samples * nslabs * G * 2 + (size_t)n_samples * C * 2) * sizeof(float);
 }
 
@@ -147,7 +154,8 @@ extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2,
     p.x = (const f16*)x; p.x2 = (const f16*)x2; p.c1 = c1; p.c2 = c2; p.ldx = ldx; p.ldx2 = ldx2;
     p.C = C; p.G = G; p.cpg = C / G; p.nvec = C / 8;
     p.n_samples = n_samples; p.rps = rows_per_sample;
-    p.nslabs = (rows_per_sample + GN_ROWS - 1) / GN_ROWS;
+    p.slab_rows = gn_slab_rows(n_samples, rows_per_sample);
+    p.nslabs = (rows_per_sample + p.slab_rows - 1) / p.slab_rows;
     p.partial = (float*)workspace;
     p.ab = p.partial + (size_t)n_samples * p.nslabs * G * 2;
     const int nt = gn_threads(p.nvec, &p.krows);

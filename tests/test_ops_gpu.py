@@ -59,7 +59,7 @@ def test_gemm_plain(gpu, M, N, K, flags):
     close(out, ref)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 6])
 def test_gemm_320_wide_kernels_all_modes(gpu, variant):
     """The 320-wide kernels in every gather mode, with M tails: variant 2 = 256x320 two-stage,
     3 = 256x320 four-stage ring (counted vmcnt), 4 = 128x320 two blocks per CU, 0 = automatic choice."""
