@@ -267,7 +267,8 @@ static int launch(const GemmP& p, hipStream_t st) {
 // Kernel choice.  `force` (vdx_gemm_args.epilogue bits 8..11, a testing/tuning knob) pins a
 // variant: 1 = 128x128 two-stage, 2 = 256x320 two-stage (K-step 64), 3 = 256x320 four-stage ring
 // (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 5 = 256x64, 6 = variant 2 without the
-// split staging roles (every wave issues its share of both operands at the top of the K tile).
+// split staging roles (every wave issues its share of both operands at the top of the K tile); 7 (handled in
+// vdx_gemm_f16) = the weights-stationary K = 320 kernel of gemm_ws.hip.
 template <int MODE, bool GEGLU>
 static int pick_tile(const GemmP& p, int force, hipStream_t st) {
     int v = force;
@@ -328,8 +329,13 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
     if (geglu) {
         VDX_CHECK(a->mode == VDX_GEMM_PLAIN && !a->bias2 && !a->residual, "gemm: GEGLU epilogue is plain-mode only");
         VDX_CHECK(a->ldo % 4 == 0, "gemm: GEGLU ldo must be a multiple of 4");
-        return pick_tile<0, true>(p, force, st);
     }
+    // K = 320 Linear layers on many rows (level 0): weights-stationary streaming kernel (variant 7 pins it)
+    if (force == 7 || (force == 0 && a->M >= 16384)) {
+        if (vdx_gemm_ws_usable(p, a->mode)) return vdx_gemm_ws_launch(p, geglu, st);
+        VDX_CHECK(force != 7, "gemm: variant 7 (weights-stationary) needs plain single-source rows, K = 320, N %% 320 == 0, M %% 64 == 0");
+    }
+    if (geglu) return pick_tile<0, true>(p, force, st);
     switch (a->mode) {
         case VDX_GEMM_PLAIN:
             return pick_tile<0, false>(p, force, st);

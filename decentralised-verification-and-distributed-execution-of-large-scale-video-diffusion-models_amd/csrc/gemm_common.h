@@ -89,3 +89,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TM][T
 // K-step-32 LDS-ring kernels (gemm_ring.hip); mode = VDX_GEMM_*; variant 0 = 256x320 tile with a
 // four-stage ring (one block per CU), variant 1 = 128x320 tile, two stages, two blocks per CU.
 int vdx_gemm_ring_launch(const GemmP& p, int mode, bool geglu, int variant, hipStream_t st);
+
+// Weights-stationary streaming kernel for K = 320 Linear layers (gemm_ws.hip).
+bool vdx_gemm_ws_usable(const GemmP& p, int mode);
+int vdx_gemm_ws_launch(const GemmP& p, bool geglu, hipStream_t st);

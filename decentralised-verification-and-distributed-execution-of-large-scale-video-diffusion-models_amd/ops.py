@@ -112,16 +112,25 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     ev0.record()
     _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
     ev1.record()
-    PROFILE.append((gemm_kernel_name(M, N, K, mode, geglu, variant), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
+    name = gemm_kernel_name(M, N, K, mode, geglu, variant, single_source=a2 is None and bias2 is None,
+                            residual=residual is not None)
+    PROFILE.append((name, 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
 
 PROFILE = None   # set to a list by bench.py to collect (kernel name, algorithmic FLOPs, start, end)
 
 
-def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: int = 0) -> str:
-    """Name of the instantiation gemm.hip's pick_tile() launches (as rocprofv3 prints it)."""
+WS_MIN_ROWS = 16384   # gemm.hip: smallest M the weights-stationary K=320 kernel is picked for
+
+
+def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: int = 0, single_source: bool = True,
+                     residual: bool = False) -> str:
+    """Name of the instantiation vdx_gemm_f16 launches (as rocprofv3 prints it)."""
     v = variant
+    ws_ok = mode == PLAIN and K == 320 and N % 320 == 0 and N // 320 <= 32 and M % 64 == 0 and single_source
+    if ws_ok and (v == 7 or (v == 0 and M >= WS_MIN_ROWS)):
+        return f"gemm_ws_kernel<{'true' if geglu else 'false'}, {'true' if residual and not geglu else 'false'}>"
     if v == 0:
         nt320 = (N + 319) // 320
         fits = nt320 * 320 * 4 <= N * 5 and M >= 1024

@@ -100,6 +100,51 @@ def test_gemm_320_wide_kernels_all_modes(gpu, variant):
     close(ops.gemm(d(rows), d(packing.pack_tconv3(w)), M=B * Fr * HW, mode=ops.TCONV3, tconv=(Fr, HW), variant=variant), ref)
 
 
+@pytest.mark.parametrize("M,N,flags", [(64, 320, "bias"), (192, 640, "none"), (4160, 960, "bias"),
+                                       (1984, 320, "bias+res"), (16448, 320, "bias+res"), (16448, 2560, "geglu"),
+                                       (704, 2560, "geglu"), (20480, 1920, "none")])
+def test_gemm_weights_stationary_k320(gpu, M, N, flags):
+    """gemm_ws.hip (K = 320 Linear layers): pinned by variant 7 on small M, picked automatically from
+    M >= 16384; uneven chunk counts per row group, 1/2/3/6/8 panels, strided A / residual / out views."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    K = 320
+    d = lambda t: t.half().to(gpu)
+    x = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = h(torch.randn(N, generator=g) * 0.3)
+    variant = 0 if M >= 16384 else 7
+    assert "gemm_ws_kernel" in ops.gemm_kernel_name(M, N, K, ops.PLAIN, flags == "geglu", variant)
+    abuf = torch.zeros(M, K + 64, dtype=torch.float16, device=gpu)     # lda > K
+    abuf[:, 32:32 + K] = d(x)
+    a_view = abuf[:, 32:32 + K]
+    if flags == "geglu":
+        a_, g_ = (x @ w.t() + b).chunk(2, dim=-1)
+        wp, bp = packing.pack_geglu(w.half(), b.half())
+        obuf = torch.full((M, N // 2 + 8), 7.0, dtype=torch.float16, device=gpu)
+        out = ops.gemm(a_view, wp.to(gpu), M=M, bias=bp.to(gpu), geglu=True, variant=variant, out=obuf[:, :N // 2])
+        close(out, a_ * F.gelu(g_))
+        assert (obuf[:, N // 2:] == 7.0).all()
+        return
+    ref = x @ w.t()
+    bias = res = None
+    if "bias" in flags:
+        bias = d(b)
+        ref = ref + b
+    if "res" in flags:
+        r = h(torch.randn(M, N, generator=g))
+        rbuf = torch.zeros(M, N + 16, dtype=torch.float16, device=gpu)
+        rbuf[:, 8:8 + N] = d(r)
+        res = rbuf[:, 8:8 + N]
+        ref = ref + r
+    obuf = torch.full((M, N + 8), 7.0, dtype=torch.float16, device=gpu)
+    out = ops.gemm(a_view, d(w), M=M, bias=bias, residual=res, variant=variant, out=obuf[:, :N])
+    close(out, ref)
+    assert (obuf[:, N:] == 7.0).all()
+    # the tiled kernel computes the same products in the same K order: identical bits
+    assert torch.equal(out, ops.gemm(a_view, d(w), M=M, bias=bias, residual=res, variant=2))
+
+
 def test_gemm_two_sources_and_strided_views(gpu):
     ops, _ = _ops()
     g = torch.Generator().manual_seed(5)

@@ -69,14 +69,18 @@ def main():
             flops = 2.0 * M * c["N"] * K
             byts = 2.0 * (M * c["cin"] + M * n_out + (M * c["N"] if res is not None else 0) + c["N"] * K)
             per = []
-            for v in (1, 2, 3, 4):
+            ws_ok = c["mode"] == ops.PLAIN and K == 320 and c["N"] % 320 == 0
+            for v in (1, 2, 3, 4, 7):
+                if v == 7 and not ws_ok:
+                    per.append(float("inf"))
+                    continue
                 fn = lambda: ops.gemm(a, wgt, M=M, mode=c["mode"], bias=bias, residual=res, out=out, variant=v,
                                       geglu=c.get("geglu", False), conv=c.get("conv"), tconv=c.get("tconv"))
                 per.append(timeit(fn))
             auto = ops.gemm_kernel_name(M, c["N"], K, c["mode"], c.get("geglu", False))
             rows.append((name, M, c["N"], K, per, flops, byts, auto))
             del a, wgt, out, res
-    names = ["128x128", "256x320", "ring4", "128x320"]
+    names = ["128x128", "256x320", "ring4", "128x320", "ws"]
     print(f"{'shape':30s} {'M':>7s} {'N':>6s} {'K':>6s} | ms: " + " ".join(f"{n:>8s}" for n in names) +
           " | best TF/s  GB/s | auto")
     for r in rows:
