@@ -165,6 +165,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
     const bool does_a = !SPLIT || wave < 4, does_w = !SPLIT || wave >= 4;
 
+    float2* gelu = (float2*)(smem + 2 * STAGE);    // GEGLU: table behind the stage buffers (first barrier publishes it)
+    if (GEGLU) gelu_tab_init(gelu, tid, NT);
     Stage sg;
     sg.setup(p, tid, m0, n0);
     if (does_w) sg.issue_w(p, smem, 0);
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 
     STAMP(2);
-    gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * WTM, n0 + wn * WTN, frow, fq);
+    gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * WTM, n0 + wn * WTN, frow, fq, gelu);
 #ifdef VDX_STAMPS
     __builtin_amdgcn_s_waitcnt(0);        // stores drained
     STAMP(3);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
 // ---- host side ------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT = false>
 static int launch(const GemmP& p, hipStream_t st) {
-    constexpr int lds = 2 * (BM + BN) * 128;
+    constexpr int lds = 2 * (BM + BN) * 128 + (GEGLU ? GELU_TAB_BYTES : 0);
     auto kern = gemm_kernel<BM, BN, WM, WN, MODE, GEGLU, SPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -268,7 +270,7 @@ static int launch(const GemmP& p, hipStream_t st) {
 // variant: 1 = 128x128 two-stage, 2 = 256x320 two-stage (K-step 64), 3 = 256x320 four-stage ring
 // (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 5 = 256x64, 6 = variant 2 without the
 // split staging roles (every wave issues its share of both operands at the top of the K tile); 7 (handled in
-// vdx_gemm_f16) = the weights-stationary K = 320 kernel of gemm_ws.hip.
+// vdx_gemm_f16) = the weights-stationary short-K kernels of gemm_ws.hip.
 template <int MODE, bool GEGLU>
 static int pick_tile(const GemmP& p, int force, hipStream_t st) {
     int v = force;
@@ -330,10 +332,12 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
         VDX_CHECK(a->mode == VDX_GEMM_PLAIN && !a->bias2 && !a->residual, "gemm: GEGLU epilogue is plain-mode only");
         VDX_CHECK(a->ldo % 4 == 0, "gemm: GEGLU ldo must be a multiple of 4");
     }
-    // K = 320 Linear layers on many rows (level 0): weights-stationary streaming kernel (variant 7 pins it)
+    // short-K Linear layers on many rows (levels 0/1, transformer_in): weights-stationary streaming kernels
+    // (variant 7 pins them)
     if (force == 7 || (force == 0 && a->M >= 16384)) {
-        if (vdx_gemm_ws_usable(p, a->mode)) return vdx_gemm_ws_launch(p, geglu, st);
-        VDX_CHECK(force != 7, "gemm: variant 7 (weights-stationary) needs plain single-source rows, K = 320, N %% 320 == 0, M %% 64 == 0");
+        const int family = vdx_gemm_ws_family(p, a->mode, geglu);
+        if (family) return vdx_gemm_ws_launch(p, family, geglu, st);
+        VDX_CHECK(force != 7, "gemm: variant 7 (weights-stationary) needs plain single-source rows, K in {320, 512, 640}, N %% 32 == 0, M %% 64 == 0");
     }
     if (geglu) return pick_tile<0, true>(p, force, st);
     switch (a->mode) {

@@ -20,8 +20,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // All side inputs of one row group (bias, time-embedding row, residual) are requested TOGETHER and
 // waited for once: issued one by one next to their use, each load was a full serialized memory
 // round trip (20 per lane per tile), which is what the short-K layers' time went to.
+// GEGLU kernels pass the block's GELU table (GELU_TAB_BYTES of LDS, filled by gelu_tab_init before a barrier).
 template <int TM, int TN, bool GEGLU>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TM][TN], int mb, int nb, int frow, int fq) {
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TM][TN], int mb, int nb, int frow, int fq,
+                                              const float2* gelu = nullptr) {
     constexpr int NA = TN / 2;
     const f16* zp = (const f16*)g_zero_page;
     // per-column bias: the same for every row group -> loaded once
@@ -74,7 +76,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TM][T
             if (GEGLU) {
                 f16x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (f16)(v[j] * gelu_erf_f(v[4 + j]));
+                for (int j = 0; j < 4; ++j) o[j] = (f16)(v[j] * gelu_tab(v[4 + j], gelu));
                 if (row_ok && n < p.N) *(f16x4*)(p.out + (size_t)m * p.ldo + (n >> 1)) = o;
             } else {
                 f16x8 o;
@@ -90,6 +92,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TM][T
 // four-stage ring (one block per CU), variant 1 = 128x320 tile, two stages, two blocks per CU.
 int vdx_gemm_ring_launch(const GemmP& p, int mode, bool geglu, int variant, hipStream_t st);
 
-// Weights-stationary streaming kernel for K = 320 Linear layers (gemm_ws.hip).
-bool vdx_gemm_ws_usable(const GemmP& p, int mode);
-int vdx_gemm_ws_launch(const GemmP& p, bool geglu, hipStream_t st);
+// Weights-stationary streaming kernels for short-K Linear layers (gemm_ws.hip): family 0 = shape not covered.
+int vdx_gemm_ws_family(const GemmP& p, int mode, bool geglu);
+int vdx_gemm_ws_launch(const GemmP& p, int family, bool geglu, hipStream_t st);

@@ -41,6 +41,8 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+    float2* gelu = (float2*)(smem + NS * STAGE);   // GEGLU: table behind the ring (the stage barriers publish it)
+    if (GEGLU) gelu_tab_init(gelu, tid, NW * 64);
 
     // ---- DMA roles.  A stage is BM/16 + 20 wave-instructions of 1 KiB (16 rows x 64 B).  Wave w
     // issues A pieces w, w+NW and B pieces w, w+NW, ... (< 20).
@@ -187,13 +189,13 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][g * 5 + j], 0, 0, 0);
         }
     }
-    gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * 64, n0 + wn * 160, frow, fq);
+    gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * 64, n0 + wn * 160, frow, fq, gelu);
 }
 
 template <int WMB, int NS, int MODE, bool GEGLU>
 int launch_ring(const GemmP& p, hipStream_t st) {
     constexpr int BM = WMB * 64;
-    constexpr int lds = NS * (BM + BN) * 64;
+    constexpr int lds = NS * (BM + BN) * 64 + (GEGLU ? GELU_TAB_BYTES : 0);
     auto kern = gemm_ring_kernel<WMB, NS, MODE, GEGLU>;
     static bool attr_set = false;
     if (!attr_set) {

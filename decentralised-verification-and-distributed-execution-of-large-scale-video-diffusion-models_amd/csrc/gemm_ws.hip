@@ -1,37 +1,39 @@
-// gemm_ws.hip — weights-stationary streaming GEMM for the level-0 Linear layers (K = 320).
+// gemm_ws.hip — weights-stationary streaming GEMM for the Linear layers with a short K (320 / 512 / 640:
+// levels 0 and 1 and transformer_in of the 3D-UNet).
 //
-//   out[M][N] = epilogue( A[M][320] . W[N][320]^T ),   N a multiple of 320, M a multiple of 64
+//   out[M][N] = epilogue( A[M][K] . W[N][K]^T ),   N a multiple of 32, M a multiple of the chunk height
 //
 // Why a second kernel: at K = 320 the tiled kernel (gemm.hip) runs five K tiles per output tile and then
 // pays a DMA prologue (~3 us), an epilogue (5-15 us) and a block turn-around (1-2 us) that nothing
 // overlaps with — one block per CU owns all the LDS — so the matrix pipe is busy ~30 % of the time
-// (tools/gemm_stamps.py).  Every output tile also re-streams its 205 KB weight panel from L2.  Here the
-// weight panel never moves:
+// (tools/gemm_stamps.py).  Every output tile also re-streams its weight panel from L2.  Here the weight
+// panel never moves:
 //
-//   * a block owns a 320-column panel of W for its whole life; each of its 10 waves keeps its
-//     32 columns x 320 K slice in REGISTERS (80 VGPRs, MFMA A-operand layout), loaded once;
-//   * activations stream through a 3-stage LDS ring in chunks of 64 rows (40 KB, LDS-DMA, counted
-//     vmcnt waits, one barrier per chunk); per chunk a wave does 40 ds_read_b128 + 80 MFMA
-//     (v_mfma_f32_16x16x32_f16) and stores its 64 x 32 outputs (16-byte stores, fused bias / residual /
-//     GEGLU) while the other waves of its SIMD keep the matrix pipe busy;
-//   * the N/320 blocks that walk the same row range sit on ONE XCD and advance together, so a chunk
+//   * a block owns a panel of 32*NW columns of W for its whole life; each of its NW waves keeps its
+//     32 columns x K slice in REGISTERS (K/4 VGPRs, MFMA A-operand layout), loaded once;
+//   * activations stream through a 3-stage LDS ring in chunks of ROWS rows (LDS-DMA, counted vmcnt waits,
+//     one barrier per chunk); per chunk a wave does ROWS/16 ds_read_b128 and ROWS/8 MFMA
+//     (v_mfma_f32_16x16x32_f16) per K step and stores its ROWS x 32 outputs (16-byte stores, fused bias /
+//     residual / GEGLU);
+//   * PIPE variants (8 waves, 256 registers each) keep TWO accumulator sets: the epilogue of chunk k-1
+//     (for GEGLU ~270 VALU instructions per lane: as long as the chunk's MFMAs) is interleaved with the
+//     MFMAs of chunk k instead of running while the matrix pipe idles behind the chunk barrier;
+//   * the blocks that walk the same row range are neighbours on one XCD and advance together, so a chunk
 //     comes from HBM once and from that XCD's L2 for the other panels.
 //
 // LDS traffic per MFMA is the same as in the tiled kernel; L2 -> LDS traffic drops from (A + W) per tile to
-// A only, and there is no per-tile prologue/epilogue bubble: the kernel is MFMA-bound for N >= 640 and
-// HBM-bound (A + out) for N = 320.
+// A only, and there is no per-tile prologue/epilogue bubble.
 #include "gemm_common.h"
 
-namespace {
+#ifdef VDX_STAMPS   // diagnostic build only: per-block cycle totals of wave 0 (wait+barrier, DMA issue, compute+epilogue)
+static __device__ unsigned long long g_ws_stamps[256 * 4];
+extern "C" int vdx_debug_read_ws_stamps(void* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_stamps), sizeof(unsigned long long) * 256 * 4) == hipSuccess ? 0 : -1;
+}
+#define WS_T() __builtin_amdgcn_s_memtime()
+#endif
 
-constexpr int WS_K = 320, WS_BN = 320, WS_ROWS = 64;
-constexpr int WS_NW = 10;                       // waves per block, 32 output columns each
-constexpr int WS_KS = WS_K / 32;                // MFMA K steps
-constexpr int WS_STAGE = WS_ROWS * WS_K * 2;    // 40 KB: 5 sub-tiles of [64 rows][128 B]
-constexpr int WS_NS = 3;                        // ring stages
-constexpr int WS_PIECES = WS_STAGE / 1024 / WS_NW;   // DMA instructions per wave and chunk (4)
-constexpr int WS_STORES = 4;                    // global stores per wave and chunk (one per 16-row group)
-static_assert(WS_PIECES * WS_NW * 1024 == WS_STAGE, "chunk must split evenly over the waves");
+namespace {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -40,123 +42,239 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 struct WsP {
     GemmP g;
-    int nt;         // 320-column panels (N / 320)
-    int gpx;        // row groups per XCD (32 / nt)
-    int nch;        // 64-row chunks in all (M / 64)
+    int nt;         // column panels
+    int groups;     // row groups (256 / nt): blocks of a group walk the same chunks
+    int nch;        // chunks in all (M / ROWS)
 };
 
-template <bool GEGLU, bool RES>
-__global__ __launch_bounds__(WS_NW * 64) void gemm_ws_kernel(const WsP q) {
-    const GemmP& p = q.g;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frow = lane & 15, fq = lane >> 4;
+template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE>
+struct Ws {
+    static constexpr int KS = K / 32;               // MFMA K steps
+    static constexpr int MT = ROWS / 16;            // 16-row groups per chunk
+    static constexpr int SUBT = ROWS * 128;         // one sub-tile: [ROWS rows][64 K-elements]
+    static constexpr int STAGE = ROWS * K * 2;      // K/64 sub-tiles
+    static constexpr int NS = 3;                    // ring stages
+    static constexpr int PPW = STAGE / 1024 / NW;   // DMA instructions per wave and chunk
+    static constexpr int RB = ROWS / 8;             // 8-row DMA blocks per sub-tile
+    static_assert(PPW * NW * 1024 == STAGE, "chunk must split evenly over the waves");
+    static_assert(NS * STAGE <= 160 * 1024, "ring exceeds the LDS");
+    typedef f32x4 Acc[MT][2];
 
-    // block -> (XCD, panel, row group): blocks b and b+8 share an XCD; the nt panels of one row group are
-    // neighbours there, so they read the same activation chunks at about the same time (L2 hits)
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int panel = idx % q.nt, group = xcd * q.gpx + idx / q.nt, groups = 8 * q.gpx;
-    const int c0 = (int)((long long)q.nch * group / groups), c1 = (int)((long long)q.nch * (group + 1) / groups);
-    const int nch = c1 - c0;
-    if (nch <= 0) return;
-    const int n0 = panel * WS_BN + wave * 32;
-
-    // ---- activation staging: chunk = 5 sub-tiles (64 K-elements each) of [64 rows][128 B]; DMA instruction
-    // i of wave w fills sub-tile w>>1, rows 8*(4*(w&1)+i) .. +7; lane l lands at row +(l>>3), slot l&7, and
-    // slot s of row r must hold data chunk s ^ (r & 7) (conflict-free ds_read_b128, as in gemm.hip)
-    const int drow = 32 * (wave & 1) + (lane >> 3);
-    const f16* a_src = p.a + (size_t)drow * p.lda + 64 * (wave >> 1) + ((lane & 7) ^ (lane >> 3)) * 8;
-    const int d_off = (wave >> 1) * 8192 + (wave & 1) * 4096;
-    auto issue = [&](int k) {   // chunk c0 + k -> ring slot k % 3
-        const f16* src = a_src + (size_t)(c0 + k) * WS_ROWS * p.lda;
-        char* dst = smem + (k % WS_NS) * WS_STAGE + d_off;
-#pragma unroll
-        for (int i = 0; i < WS_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(8 * i) * p.lda), (lptr_t)(dst + i * 1024), 16, 0, 0);
-    };
-    issue(0);
-    if (nch > 1) issue(1);
-
-    // ---- this wave's weight slice, MFMA A-operand layout.  MFMA row i of 16-column tile j carries
-    // weight row n0 + 8*(i>>2) + 4*j + (i&3): the lane then owns 8 CONSECUTIVE output columns
-    // (n0 + 8*fq .. +7) of row frow -> 16-byte stores.
-    f16x8 wf[WS_KS][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const f16* wrow = p.w + (size_t)(n0 + 8 * (frow >> 2) + 4 * j + (frow & 3)) * WS_K + 8 * fq;
-#pragma unroll
-        for (int s = 0; s < WS_KS; ++s) wf[s][j] = *(const f16x8*)(wrow + 32 * s);
-    }
+    const GemmP& p;
+    char* smem;
+    const float2* gelu;          // GEGLU: table of the normal CDF behind the ring (published by the first chunk barrier)
+    int lane, wave, frow, fq, n0, c0, nch;
+    bool active;                 // this wave's 32 columns exist (last panel of an N that is no panel multiple)
+    const f16* a_src;            // this lane's DMA source for row (lane>>3) of 8-row block 0, sub-tile 0
+    f16x8 wf[KS][2];
     f16x8 bv;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = (f16)0.f;
-    if (p.bias) bv = *(const f16x8*)(p.bias + n0 + 8 * fq);
+#ifdef VDX_STAMPS
+    unsigned long long t_bar = 0, t_iss = 0, t_wait = 0, t_last = 0;
+#endif
 
-    const int a_rd = frow * 128;   // + sub-tile, + 16-row group, + swizzled slot
-    for (int k = 0; k < nch; ++k) {
-        // chunk k has landed once at most the operations issued after its DMA are outstanding:
-        // the stores of chunks k-2 and k-1 and the DMA of chunk k+1 (vector-memory operations retire in order)
-        const int younger = (k + 1 < nch ? WS_PIECES : 0) + (k >= 1 ? WS_STORES : 0) + (k >= 2 ? WS_STORES : 0);
-        if (younger >= WS_PIECES + 2 * WS_STORES) wait_vmcnt<WS_PIECES + 2 * WS_STORES>();
-        else if (younger >= 2 * WS_STORES) wait_vmcnt<2 * WS_STORES>();
-        else if (younger >= WS_PIECES) wait_vmcnt<(WS_PIECES < WS_STORES ? WS_PIECES : WS_STORES)>();
+    __device__ __forceinline__ Ws(const GemmP& p_, char* smem_) : p(p_), smem(smem_) {}
+
+    // chunk c0 + k -> ring slot k % NS.  DMA instruction i of wave w is piece w*PPW + i: sub-tile
+    // piece / RB, rows 8*(piece % RB) .. +7; lane l lands at row +(l>>3), slot l&7, and slot s of row r
+    // must hold data chunk s ^ (r & 7) (conflict-free ds_read_b128, as in gemm.hip)
+    __device__ __forceinline__ void issue(int k) {
+        const f16* src = a_src + (size_t)(c0 + k) * ROWS * p.lda;
+        char* dst = smem + (k % NS) * STAGE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave * PPW + i, q = piece / RB, rb = piece % RB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(8 * rb) * p.lda + 64 * q),
+                                             (lptr_t)(dst + q * SUBT + rb * 1024), 16, 0, 0);
+        }
+    }
+    // Chunk k has landed once at most the operations issued after its DMA are outstanding (vector-memory
+    // operations retire in order): the DMA of chunk k+1 and the stores of the two epilogues issued since
+    // (chunks k-2, k-1; with PIPE, whose epilogue runs one chunk later: k-3, k-2).  Residual loads are
+    // not counted: they have been consumed, and counting fewer only waits longer.
+    __device__ __forceinline__ void sync(int k) {
+        constexpr int LAG = PIPE ? 1 : 0;
+        const bool d = k + 1 < nch, s1 = active && k >= 1 + LAG, s2 = active && k >= 2 + LAG;   // idle waves store nothing
+        if (d && s2) wait_vmcnt<PPW + 2 * MT>();
+        else if (d && s1) wait_vmcnt<PPW + MT>();
+        else if (d) wait_vmcnt<PPW>();
+        else if (s2) wait_vmcnt<2 * MT>();
+        else if (s1) wait_vmcnt<MT>();
         else wait_vmcnt<0>();
+#ifdef VDX_STAMPS
+        const unsigned long long t0 = WS_T();
+#endif
         __builtin_amdgcn_s_barrier();     // everyone's part of chunk k landed; everyone is past chunk k-1
+#ifdef VDX_STAMPS
+        const unsigned long long t1 = WS_T();
+#endif
         if (k + 2 < nch) issue(k + 2);    // into the ring slot chunk k-1 just vacated
-
-        const char* st = smem + (k % WS_NS) * WS_STAGE + a_rd;
-        f32x4 acc[4][2];
+#ifdef VDX_STAMPS
+        const unsigned long long t2 = WS_T();
+        t_bar += t1 - t0;
+        t_iss += t2 - t1;
+        t_wait += t0 - t_last;    // (includes the compute of the previous chunk: subtract t_cmp)
+        t_last = t2;
+#endif
+    }
+    __device__ __forceinline__ void zero(Acc& acc) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void load_af(const char* st, int s, f16x8 (&af)[MT]) {
+        const int c = (s & 1) * 4 + fq;
 #pragma unroll
-        for (int s = 0; s < WS_KS; ++s) {
-            const int c = (s & 1) * 4 + fq;
-            f16x8 af[4];
+        for (int i = 0; i < MT; ++i)   // row = 16*i + frow, so row & 7 == frow & 7
+            af[i] = *(const f16x8*)(st + (s >> 1) * SUBT + i * 2048 + ((c ^ (frow & 7)) << 4));
+    }
+    __device__ __forceinline__ void mfma_step(int s, const f16x8 (&af)[MT], Acc& acc) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)   // row = 16*i + frow, so row & 7 == frow & 7
-                af[i] = *(const f16x8*)(st + (s >> 1) * 8192 + i * 2048 + ((c ^ (frow & 7)) << 4));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], af[i], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], af[i], acc[i][1], 0, 0, 0);
-            }
+        for (int i = 0; i < MT; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], af[i], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], af[i], acc[i][1], 0, 0, 0);
         }
-
-        // ---- epilogue of this chunk: exactly WS_STORES stores per wave (the wait above counts them)
-        const size_t m = (size_t)(c0 + k) * WS_ROWS + frow;
-        f16x8 rv[4];
-        if (RES) {
+    }
+    __device__ __forceinline__ void load_res(int k, f16x8 (&rv)[MT]) {
+        const size_t m = (size_t)(c0 + k) * ROWS + frow;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rv[i] = *(const f16x8*)(p.res + (m + 16 * i) * p.ldr + n0 + 8 * fq);
+        for (int i = 0; i < MT; ++i) rv[i] = *(const f16x8*)(p.res + (m + 16 * i) * p.ldr + n0 + 8 * fq);
+    }
+    // row group i of chunk k: exactly one store (the waits in sync() count them)
+    __device__ __forceinline__ void store_group(int k, int i, const Acc& acc, const f16x8 (&rv)[MT]) {
+        const size_t m = (size_t)(c0 + k) * ROWS + frow + 16 * i;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = acc[i][0][j] + (float)bv[j];
+            v[4 + j] = acc[i][1][j] + (float)bv[4 + j];
         }
+        if (GEGLU) {
+            f16x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v[8];
+            for (int j = 0; j < 4; ++j) o[j] = (f16)(v[j] * gelu_tab(v[4 + j], gelu));
+            *(f16x4*)(p.out + m * p.ldo + ((n0 + 8 * fq) >> 1)) = o;
+        } else {
+            f16x8 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = acc[i][0][j] + (float)bv[j];
-                v[4 + j] = acc[i][1][j] + (float)bv[4 + j];
-            }
-            if (GEGLU) {
-                f16x4 o;
+            for (int j = 0; j < 8; ++j) o[j] = (f16)(RES ? v[j] + (float)rv[i][j] : v[j]);
+            *(f16x8*)(p.out + m * p.ldo + n0 + 8 * fq) = o;
+        }
+    }
+    // MFMAs of chunk k into `cur`, with the epilogue of chunk k-1 (from `prev`) spread between them
+    template <bool HAS_PREV>
+    __device__ __forceinline__ void step(int k, Acc& cur, const Acc& prev) {
+        const char* st = smem + (k % NS) * STAGE + frow * 128;
+        f16x8 rv[MT];
+        if (RES && HAS_PREV) load_res(k - 1, rv);
+        zero(cur);
+        if (!active) return;
+        // (reading the fragments of K step s+1 before the MFMAs of step s was measured: no gain — the other
+        // wave(s) of the SIMD already cover the LDS latency)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (f16)(v[j] * gelu_erf_f(v[4 + j]));
-                *(f16x4*)(p.out + (m + 16 * i) * p.ldo + ((n0 + 8 * fq) >> 1)) = o;
-            } else {
-                f16x8 o;
+        for (int s = 0; s < KS; ++s) {
+            f16x8 af[MT];
+            load_af(st, s, af);
+            mfma_step(s, af, cur);
+            if (HAS_PREV) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)(RES ? v[j] + (float)rv[i][j] : v[j]);
-                *(f16x8*)(p.out + (m + 16 * i) * p.ldo + n0 + 8 * fq) = o;
+                for (int i = 0; i < MT; ++i)
+                    if (s + 1 == KS * (i + 1) / MT) store_group(k - 1, i, prev, rv);
             }
         }
     }
+    __device__ __forceinline__ void drain(int k, const Acc& acc) {
+        if (!active) return;
+        f16x8 rv[MT];
+        if (RES) load_res(k, rv);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) store_group(k, i, acc, rv);
+    }
+
+    __device__ __forceinline__ void run(const WsP& q) {
+        const int tid = threadIdx.x;
+        gelu = (const float2*)(smem + NS * STAGE);
+        if (GEGLU) gelu_tab_init((float2*)(smem + NS * STAGE), tid, NW * 64);
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        frow = lane & 15;
+        fq = lane >> 4;
+        // block -> (row group, panel): blocks b and b+8 share an XCD, so linear slot (b&7)*32 + (b>>3)
+        // keeps the panels of one row group next to each other on one XCD (L2 hits on their common chunks)
+        const int slot = (blockIdx.x & 7) * 32 + (blockIdx.x >> 3);
+        const int group = slot / q.nt, panel = slot - group * q.nt;
+        if (group >= q.groups) return;
+        c0 = (int)((long long)q.nch * group / q.groups);
+        nch = (int)((long long)q.nch * (group + 1) / q.groups) - c0;
+        if (nch <= 0) return;
+        n0 = panel * (32 * NW) + wave * 32;
+        active = n0 < p.N;
+        a_src = p.a + (size_t)(lane >> 3) * p.lda + ((lane & 7) ^ (lane >> 3)) * 8;
+        issue(0);
+        if (nch > 1) issue(1);
+#ifdef VDX_STAMPS
+        t_last = WS_T();
+#endif
+
+        // this wave's weight slice, MFMA A-operand layout.  MFMA row i of 16-column tile j carries weight
+        // row n0 + 8*(i>>2) + 4*j + (i&3): the lane then owns 8 CONSECUTIVE output columns
+        // (n0 + 8*fq .. +7) of row frow -> 16-byte stores.
+        const int nw = active ? n0 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f16* wrow = p.w + (size_t)(nw + 8 * (frow >> 2) + 4 * j + (frow & 3)) * K + 8 * fq;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wf[s][j] = *(const f16x8*)(wrow + 32 * s);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = (f16)0.f;
+        if (p.bias && active) bv = *(const f16x8*)(p.bias + n0 + 8 * fq);
+
+        if (!PIPE) {
+            for (int k = 0; k < nch; ++k) {
+                sync(k);
+                Acc acc;
+                step<false>(k, acc, acc);
+                drain(k, acc);
+            }
+        } else {
+            Acc a, b;
+            sync(0);
+            step<false>(0, a, a);
+            int k = 1;
+            for (; k + 1 < nch; k += 2) {
+                sync(k);
+                step<true>(k, b, a);
+                sync(k + 1);
+                step<true>(k + 1, a, b);
+            }
+            if (k < nch) {                 // nch even: chunk nch-1 goes into b, then drain b
+                sync(k);
+                step<true>(k, b, a);
+                drain(k, b);
+            } else {                       // nch odd: the last chunk is in a
+                drain(nch - 1, a);
+            }
+        }
+#ifdef VDX_STAMPS
+        if (threadIdx.x == 0) {
+            unsigned long long* d = g_ws_stamps + blockIdx.x * 4;
+            d[0] = t_bar; d[1] = t_iss; d[2] = t_wait; d[3] = (unsigned long long)nch;
+        }
+#endif
+    }
+};
+
+template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE>
+__global__ __launch_bounds__(NW * 64) void gemm_ws_kernel(const WsP q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ws<K, NW, ROWS, GEGLU, RES, PIPE> ws(q.g, smem);
+    ws.run(q);
 }
 
-template <bool GEGLU, bool RES>
+template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE>
 int launch_ws(const GemmP& p, hipStream_t st) {
-    constexpr int lds = WS_NS * WS_STAGE;
-    auto kern = gemm_ws_kernel<GEGLU, RES>;
+    typedef Ws<K, NW, ROWS, GEGLU, RES, PIPE> W;
+    constexpr int lds = W::NS * W::STAGE + (GEGLU ? GELU_TAB_BYTES : 0);
+    auto kern = gemm_ws_kernel<K, NW, ROWS, GEGLU, RES, PIPE>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -165,23 +283,40 @@ int launch_ws(const GemmP& p, hipStream_t st) {
     }
     WsP q;
     q.g = p;
-    q.nt = p.N / WS_BN;
-    q.gpx = 32 / q.nt;                 // 256 CUs = 8 XCDs x 32: one block per CU
-    q.nch = p.M / WS_ROWS;
-    hipLaunchKernelGGL(kern, dim3(8 * q.gpx * q.nt), dim3(WS_NW * 64), lds, st, q);
+    q.nt = (p.N + 32 * NW - 1) / (32 * NW);
+    q.groups = 256 / q.nt;               // 256 CUs: one block per CU
+    q.nch = p.M / ROWS;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16 (weights-stationary)");
+}
+
+template <int K, int NW, int ROWS, bool PIPE>
+int launch_ws_epi(const GemmP& p, bool geglu, hipStream_t st) {
+    if (geglu) return launch_ws<K, NW, ROWS, true, false, PIPE>(p, st);
+    return p.res ? launch_ws<K, NW, ROWS, false, true, PIPE>(p, st) : launch_ws<K, NW, ROWS, false, false, PIPE>(p, st);
 }
 
 }  // namespace
 
-// usable(): plain single-source rows, K = 320, whole 320-column panels (at most 32: one XCD holds all
-// panels of a row group), whole 64-row chunks, no per-row-block bias
-bool vdx_gemm_ws_usable(const GemmP& p, int mode) {
-    return mode == VDX_GEMM_PLAIN && p.K == WS_K && p.c2 == 0 && p.N % WS_BN == 0 && p.N / WS_BN <= 32 &&
-           p.M % WS_ROWS == 0 && p.bias2 == nullptr;
+// Shape family: 0 = not usable; 1 = K 320, 10 waves (320-column panels, N % 320 == 0);
+// 2 = K 320, 8 waves pipelined (256-column panels); 3 = K 512; 4 = K 640 (both 8 waves pipelined, 32-row chunks)
+int vdx_gemm_ws_family(const GemmP& p, int mode, bool geglu) {
+    if (mode != VDX_GEMM_PLAIN || p.c2 != 0 || p.bias2 != nullptr || p.N % 32 != 0 || p.N > 256 * 256) return 0;
+    if (p.K == 320 && p.M % 64 == 0) {
+        if (p.N % 320 == 0 && !(geglu && p.N % 256 == 0)) return 1;
+        return 2;
+    }
+    if (p.K == 512 && p.M % 32 == 0 && p.N % 256 == 0) return 3;   // (512 -> 320: the 64-column last panel loses to the tiled kernel)
+    if (p.K == 640 && p.M % 32 == 0) return 4;
+    return 0;
 }
 
-int vdx_gemm_ws_launch(const GemmP& p, bool geglu, hipStream_t st) {
-    if (geglu) return launch_ws<true, false>(p, st);
-    return p.res ? launch_ws<false, true>(p, st) : launch_ws<false, false>(p, st);
+int vdx_gemm_ws_launch(const GemmP& p, int family, bool geglu, hipStream_t st) {
+    switch (family) {
+        case 1: return launch_ws_epi<320, 10, 64, false>(p, geglu, st);
+        case 2: return launch_ws_epi<320, 8, 64, true>(p, geglu, st);
+        case 3: return launch_ws_epi<512, 8, 32, true>(p, geglu, st);
+        case 4: return launch_ws_epi<640, 8, 32, true>(p, geglu, st);
+    }
+    return vdx_fail("gemm_ws: shape not supported");
 }

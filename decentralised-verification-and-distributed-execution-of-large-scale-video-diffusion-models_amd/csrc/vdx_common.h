@@ -54,6 +54,29 @@ __device__ __forceinline__ float erf_fast(float x) {
 __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f));
 }
+// GELU through a table of the normal CDF in LDS (the GEGLU epilogues).  Evaluating erf costs ~17 VALU
+// instructions, two of them quarter-rate, per output: at K = 320 that is as many issue cycles as the
+// output's MFMAs, and the feed-forward GEMMs were VALU-bound.  The table holds (Phi(x_i), Phi(x_i+1) -
+// Phi(x_i)) on [-5, 5) in steps of 10/1024; linear interpolation is exact to 3e-6 (h^2/8 * max|Phi''|),
+// far below the fp16 rounding of the result, and costs 8 VALU instructions and one ds_read_b64.
+#define GELU_TAB_N 1024
+#define GELU_TAB_BYTES (GELU_TAB_N * 8)
+__device__ __forceinline__ void gelu_tab_init(float2* tab, int tid, int nthreads) {
+    const float h = 10.0f / GELU_TAB_N;
+    for (int i = tid; i < GELU_TAB_N; i += nthreads) {
+        const float x0 = -5.0f + i * h;
+        const float p0 = 0.5f * (1.0f + erf_fast(x0 * 0.70710678118654752f));
+        const float p1 = 0.5f * (1.0f + erf_fast((x0 + h) * 0.70710678118654752f));
+        tab[i] = make_float2(p0, p1 - p0);
+    }
+}
+__device__ __forceinline__ float gelu_tab(float x, const float2* tab) {
+    float u = fmaf(x, GELU_TAB_N / 10.0f, GELU_TAB_N / 2.0f);
+    u = fminf(fmaxf(u, 0.0f), GELU_TAB_N - 0.001f);
+    const float fi = floorf(u);
+    const float2 e = tab[(int)fi];
+    return x * fmaf(u - fi, e.y, e.x);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -128,9 +128,15 @@ def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: in
                      residual: bool = False) -> str:
     """Name of the instantiation vdx_gemm_f16 launches (as rocprofv3 prints it)."""
     v = variant
-    ws_ok = mode == PLAIN and K == 320 and N % 320 == 0 and N // 320 <= 32 and M % 64 == 0 and single_source
-    if ws_ok and (v == 7 or (v == 0 and M >= WS_MIN_ROWS)):
-        return f"gemm_ws_kernel<{'true' if geglu else 'false'}, {'true' if residual and not geglu else 'false'}>"
+    if single_source and mode == PLAIN and N % 32 == 0 and (v == 7 or (v == 0 and M >= WS_MIN_ROWS)):
+        fam = None   # mirrors vdx_gemm_ws_family (gemm_ws.hip): (K, waves, chunk rows, pipelined)
+        if K == 320 and M % 64 == 0:
+            fam = (320, 10, 64, False) if (N % 320 == 0 and not (geglu and N % 256 == 0)) else (320, 8, 64, True)
+        elif ((K == 512 and N % 256 == 0) or K == 640) and M % 32 == 0:
+            fam = (K, 8, 32, True)
+        if fam:
+            b = lambda x: "true" if x else "false"
+            return f"gemm_ws_kernel<{fam[0]}, {fam[1]}, {fam[2]}, {b(geglu)}, {b(residual and not geglu)}, {b(fam[3])}>"
     if v == 0:
         nt320 = (N + 319) // 320
         fits = nt320 * 320 * 4 <= N * 5 and M >= 1024

@@ -100,15 +100,18 @@ def test_gemm_320_wide_kernels_all_modes(gpu, variant):
     close(ops.gemm(d(rows), d(packing.pack_tconv3(w)), M=B * Fr * HW, mode=ops.TCONV3, tconv=(Fr, HW), variant=variant), ref)
 
 
-@pytest.mark.parametrize("M,N,flags", [(64, 320, "bias"), (192, 640, "none"), (4160, 960, "bias"),
-                                       (1984, 320, "bias+res"), (16448, 320, "bias+res"), (16448, 2560, "geglu"),
-                                       (704, 2560, "geglu"), (20480, 1920, "none")])
-def test_gemm_weights_stationary_k320(gpu, M, N, flags):
-    """gemm_ws.hip (K = 320 Linear layers): pinned by variant 7 on small M, picked automatically from
-    M >= 16384; uneven chunk counts per row group, 1/2/3/6/8 panels, strided A / residual / out views."""
+@pytest.mark.parametrize("M,N,K,flags", [
+    (64, 320, 320, "bias"), (192, 640, 320, "none"), (4160, 960, 320, "bias"), (1984, 320, 320, "bias+res"),
+    (16448, 320, 320, "bias+res"), (704, 1600, 320, "geglu"), (20480, 1920, 320, "none"),      # 10 waves, 320-wide panels
+    (16448, 2560, 320, "geglu"), (704, 2560, 320, "geglu"), (1088, 512, 320, "bias"),           # 8 waves, pipelined epilogue
+    (320, 1536, 512, "none"), (16416, 512, 512, "bias+res"), (2080, 4096, 512, "geglu"), (992, 768, 512, "bias+res"),
+    (160, 640, 640, "bias+res"), (16416, 1920, 640, "none"), (2080, 5120, 640, "geglu"), (96, 1280, 640, "bias")])
+def test_gemm_weights_stationary(gpu, M, N, K, flags):
+    """gemm_ws.hip (short-K Linear layers, K in {320, 512, 640}): pinned by variant 7 on small M, picked
+    automatically from M >= 16384; odd/even/uneven chunk counts per row group, partial last panels, strided
+    A / residual / out views."""
     ops, packing = _ops()
-    g = torch.Generator().manual_seed(M + N)
-    K = 320
+    g = torch.Generator().manual_seed(M + N + K)
     d = lambda t: t.half().to(gpu)
     x = h(torch.randn(M, K, generator=g))
     w = h(torch.randn(N, K, generator=g) / math.sqrt(K))

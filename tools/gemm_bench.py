@@ -69,7 +69,7 @@ def main():
             flops = 2.0 * M * c["N"] * K
             byts = 2.0 * (M * c["cin"] + M * n_out + (M * c["N"] if res is not None else 0) + c["N"] * K)
             per = []
-            ws_ok = c["mode"] == ops.PLAIN and K == 320 and c["N"] % 320 == 0
+            ws_ok = c["mode"] == ops.PLAIN and K in (320, 512, 640)
             for v in (1, 2, 3, 4, 7):
                 if v == 7 and not ws_ok:
                     per.append(float("inf"))
