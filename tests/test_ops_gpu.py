@@ -275,7 +275,7 @@ def _attn_ref(q, k, v, heads):
     return o.transpose(1, 2).reshape(n * s, heads * 64)
 
 
-@pytest.mark.parametrize("n_seq,s,heads", [(3, 144, 2), (2, 64, 1), (2, 200, 3), (1, 576, 2)])
+@pytest.mark.parametrize("n_seq,s,heads", [(3, 144, 2), (2, 64, 1), (2, 200, 3), (1, 576, 2), (1, 4096, 2)])
 def test_flash_self_attention(gpu, n_seq, s, heads):
     ops, _ = _ops()
     g = torch.Generator().manual_seed(n_seq + s)
