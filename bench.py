@@ -31,6 +31,21 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 TFLOP_PER_STEP_24F = 156.97      # algorithmic FLOPs of one CFG step at 24 f, XL
+PMC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_ws.json")
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
+    (FETCH_SIZE x2-corrected + WRITE_SIZE, tools/pmc_summary.py --json): counters cannot be read from inside
+    the bench process.  None when the profile does not list the kernel."""
+    try:
+        import json as _json
+        e = _json.load(open(PMC_JSON)).get(kernel)
+        return round(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]) if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 PEAK_MFMA_TFLOPS = 2500.0        # gfx950 dense fp16/bf16 matrix peak (MI355X_MICROARCH.md)
 
 
@@ -191,7 +206,7 @@ def main():
             name, (fl, ms, n) = max(agg.items(), key=lambda kv: kv[1][1])
             ach = fl / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None, "kernel": name,
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(name), "kernel": name,
                                "launches": n, "avg_launch_ms": round(ms / n, 4),
                                "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}
             out["gemm_kernels"] = {k: {"launches": v[2], "ms": round(v[1], 2), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}

@@ -26,7 +26,7 @@ def load(d):
     n = collections.Counter()
     seen = set()
     for r in csv.DictReader(open(f[0])):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (r["Dispatch_Id"])
         if key not in seen:
@@ -39,7 +39,13 @@ def load(d):
 def main():
     merged = collections.defaultdict(dict)
     durs, counts = {}, {}
-    for d in sys.argv[1:]:
+    args = sys.argv[1:]
+    json_out = None
+    if "--json" in args:            # per-kernel HBM bytes per launch, for bench.py's roofline.traffic
+        i = args.index("--json")
+        json_out = args[i + 1]
+        del args[i:i + 2]
+    for d in args:
         per, dur, n = load(d)
         for k, c in per.items():
             for name, v in c.items():
@@ -59,11 +65,15 @@ def main():
         rows.append((durs[k], k, counts[k], rd, wr, bw, util))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
+    if json_out:
+        import json
+        json.dump({k: {"launches": n, "hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n,
+                       "mfma_busy": util} for t, k, n, rd, wr, bw, util in rows if n}, open(json_out, "w"), indent=1)
     print("| kernel | launches | time share | HBM read GB (x2-corrected) | HBM write GB | HBM GB/s | MFMA busy |")
     print("|---|---|---|---|---|---|---|")
-    for t, k, n, rd, wr, bw, util in rows[:24]:
+    for t, k, n, rd, wr, bw, util in rows[:32]:
         u = f"{100 * util:.1f} %" if util is not None else "-"
-        print(f"| `{k[:60]}` | {n} | {100 * t / tot:.1f} % | {rd / 1e9:.2f} | {wr / 1e9:.2f} | {bw / 1e9:.0f} | {u} |")
+        print(f"| `{k[:72]}` | {n} | {100 * t / tot:.1f} % | {rd / 1e9:.2f} | {wr / 1e9:.2f} | {bw / 1e9:.0f} | {u} |")
 
 
 if __name__ == "__main__":
