@@ -33,6 +33,8 @@ SIGNATURES = {
     "vdx_last_error": (C.c_char_p, []),
     "vdx_version": (_i, []),
     "vdx_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
+    "vdx_softmax_rows_f16": (_i, [_vp, _i, _i, _i, _f, _vp]),
+    "vdx_rows_to_u8_frames": (_i, [_vp, _i, _sz, _vp, _vp]),
     "vdx_im2col_in_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vdx_rows_to_ncfhw_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "vdx_silu_f16": (_i, [_vp, _vp, _sz, _vp]),

@@ -214,3 +214,31 @@ extern "C" int vdx_blend_finalize_f32(const void* full, const float* weight, flo
                        out, C, T, HW);
     return vdx_launch_status("vdx_blend_finalize_f32");
 }
+
+// ---- decoded frames -> uint8 HWC  (fsdp_chunked_coherent.py:224-225):
+//   img = (sample.permute(1,2,0) * 0.5 + 0.5).clamp(0, 1);  frame = (img * 255).byte()
+// Every torch op rounds to fp16 (opmath fp32); .byte() truncates.  Input: the decoder's channels-last rows
+// [pixels][ld] (first 3 columns = RGB), so the NCHW sample never has to exist for the video path.
+__global__ void rows_to_u8_kernel(const f16* rows, int ld, size_t npix, unsigned char* out) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const f16* src = rows + p * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const f16 a = rn16(__fmul_rn((float)src[c], 0.5f));
+        f16 b = rn16(__fadd_rn((float)a, 0.5f));
+        b = (f16)fminf(fmaxf((float)b, 0.f), 1.f);
+        const f16 d = rn16(__fmul_rn((float)b, 255.f));
+        out[p * 3 + c] = (unsigned char)(int)(float)d;
+    }
+}
+
+extern "C" int vdx_rows_to_u8_frames(const void* rows, int ld, size_t n_pixels, void* out_u8, vdx_stream_t stream) {
+    VDX_CHECK(rows && out_u8, "rows_to_u8_frames: null pointer");
+    VDX_CHECK(ld >= 3 && n_pixels > 0, "rows_to_u8_frames: bad shape");
+    const size_t blocks = (n_pixels + 255) / 256;
+    VDX_CHECK(blocks < (1ull << 31), "rows_to_u8_frames: too many pixels");
+    hipLaunchKernelGGL(rows_to_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)rows, ld, n_pixels, (unsigned char*)out_u8);
+    return vdx_launch_status("vdx_rows_to_u8_frames");
+}

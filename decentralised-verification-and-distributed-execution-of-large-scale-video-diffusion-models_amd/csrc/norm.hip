@@ -237,3 +237,72 @@ extern "C" int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, cons
 #undef LN_LAUNCH
     return vdx_launch_status("vdx_layernorm_f16");
 }
+
+// ---- row softmax, in place (AutoencoderKL mid-block attention: one head of 512 channels over h*w tokens; the
+// [tokens][tokens] score matrix is a plain GEMM, this kernel, and a second GEMM).  One block per row, the row
+// lives in registers (<= 8 vectors of 8 per thread = 16384 columns): 1 read + 1 write.  Scores are scaled in
+// fp32 (diffusers: baddbmm alpha, upcast softmax), probabilities rounded to fp16 once.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(f16* x, int ld, int cols, float c /* scale*log2(e) */) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, nvec = cols >> 3;
+    f16* xr = x + (size_t)blockIdx.x * ld;
+    f16x8 v[NV];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cv = tid + 256 * i;
+        if (cv < nvec) {
+            v[i] = *(const f16x8*)(xr + cv * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, (float)v[i][j]);
+        }
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // scale > 0: max commutes with it
+    float e[NV][8], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (tid + 256 * i < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                e[i][j] = __builtin_amdgcn_exp2f(((float)v[i][j] - m) * c);
+                sum += e[i][j];
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cv = tid + 256 * i;
+        if (cv < nvec) {
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)(e[i][j] * inv);
+            *(f16x8*)(xr + cv * 8) = o;
+        }
+    }
+}
+
+extern "C" int vdx_softmax_rows_f16(void* x, int ld, int rows, int cols, float scale, vdx_stream_t stream) {
+    VDX_CHECK(x, "softmax_rows: null pointer");
+    VDX_CHECK(rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "softmax_rows: bad shape rows=%d cols=%d ld=%d", rows, cols, ld);
+    VDX_CHECK(scale > 0.f, "softmax_rows: scale must be positive");
+    const int nv = (cols / 8 + 255) / 256;
+    VDX_CHECK(nv <= 8, "softmax_rows: %d columns exceed 16384", cols);
+    hipStream_t st = (hipStream_t)stream;
+    const float c = scale * 1.44269504088896341f;
+#define SM_LAUNCH(NV) hipLaunchKernelGGL(softmax_rows_kernel<NV>, dim3(rows), dim3(256), 0, st, (f16*)x, ld, cols, c)
+    if (nv <= 1) SM_LAUNCH(1);
+    else if (nv <= 2) SM_LAUNCH(2);
+    else if (nv <= 5) SM_LAUNCH(5);
+    else SM_LAUNCH(8);
+#undef SM_LAUNCH
+    return vdx_launch_status("vdx_softmax_rows_f16");
+}

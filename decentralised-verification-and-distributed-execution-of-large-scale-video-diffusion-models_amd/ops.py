@@ -250,6 +250,28 @@ def layernorm(x, gamma, beta, *, M, eps=1e-5, out=None):
     return out
 
 
+def softmax_rows(x, *, rows, cols, scale):
+    """In-place softmax(scale * x[r, :cols]) per row (fp32 inside): AutoencoderKL mid-block attention."""
+    lib = _lib.load()
+    r, c, ld = _rows(x, "x")
+    if r < rows or c < cols:
+        raise VdxError("softmax_rows: x too small")
+    _lib.check(lib.vdx_softmax_rows_f16(_p(x, "x"), ld, rows, cols, float(scale), _stream()), "vdx_softmax_rows_f16")
+    return x
+
+
+def rows_to_u8_frames(rows, n, H, W):
+    """Decoder output rows [n*H*W][ld] (RGB first) -> uint8 (n,H,W,3): fsdp_chunked_coherent.py:224-225."""
+    lib = _lib.load()
+    r, c, ld = _rows(rows, "rows")
+    if r < n * H * W or c < 3:
+        raise VdxError("rows_to_u8_frames: rows too small")
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=rows.device)
+    _lib.check(lib.vdx_rows_to_u8_frames(_p(rows, "rows"), ld, n * H * W, out.data_ptr(), _stream()),
+               "vdx_rows_to_u8_frames")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, out=None):
     """q rows [n_seq*sq][>=heads*64]; k rows [n_kv*skv_pad][>=heads*64]; vt [heads*64][>= n_kv*skv_pad]."""

@@ -146,6 +146,19 @@ class DistributedVideoDiffuser:
             ops.blend_accumulate(full, weight, lat.contiguous(), ramp_weights(e - s, ov).to(like.device), s, e)
         return ops.blend_finalize(full, weight)
 
+    def decode_frames(self, lat: torch.Tensor, vae, batch: int = 8) -> List:
+        """Reference :219-225: the blended latent (1,C,T,h,w) -> T uint8 (H,W,3) frames (numpy, host).
+        `z/0.18215` is formed in the latent's dtype and cast to fp16 at the VAE boundary (what the reference's
+        FSDP mixed-precision wrapper does to forward inputs); frames are decoded `batch` at a time instead of one
+        by one (frames are independent samples of the decoder)."""
+        frames = []
+        T = lat.shape[2]
+        for i0 in range(0, T, batch):
+            z = lat[0, :, i0:i0 + batch].permute(1, 0, 2, 3) / 0.18215
+            u8 = vae.decode_frames_u8(z.to(self.cfg.device, torch.float16).contiguous())
+            frames += [f for f in u8.cpu().numpy()]
+        return frames
+
     def __call__(self):
         cfg = self.cfg
         T, H, W = cfg.num_frames, cfg.height // 8, cfg.width // 8

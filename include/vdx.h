@@ -92,6 +92,11 @@ int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, in
                       const void* gamma, const void* beta, float eps, int G,
                       int n_samples, int rows_per_sample, int silu,
                       void* y, int ldy, void* workspace, vdx_stream_t stream);
+/* In-place softmax over the first `cols` columns of each of `rows` rows of x (row stride ld), logits scaled by
+ * `scale` in fp32: the probabilities of AutoencoderKL's mid-block attention (one 512-channel head over h*w
+ * tokens; diffusers Attention with upcast softmax), reached from fsdp_chunked_coherent.py:223.            */
+int vdx_softmax_rows_f16(void* x, int ld, int rows, int cols, float scale, vdx_stream_t stream);
+
 int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps,
                       int M, int C, void* y, int ldy, vdx_stream_t stream);
 
@@ -138,6 +143,11 @@ int vdx_blend_accumulate_f16(void* full, float* weight, const void* chunk, const
 /* :217 lat = full / clamp(weight, 1e-6) -> fp32                                                */
 int vdx_blend_finalize_f32(const void* full, const float* weight, float* out, int C, int T,
                            int HW, vdx_stream_t stream);
+
+/* Decoded frames -> uint8 HWC exactly as fsdp_chunked_coherent.py:224-225 maps them
+ * ((sample*0.5+0.5).clamp(0,1), *255, .byte(); fp16 rounding after every op, truncation at the end).
+ * rows: the decoder's channels-last output rows [n_pixels][ld], RGB in the first 3 columns.            */
+int vdx_rows_to_u8_frames(const void* rows, int ld, size_t n_pixels, void* out_u8, vdx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 from oracle.ddim_ref import DDIMSchedulerRef  # noqa: E402
 from oracle.pipeline_ref import run_video  # noqa: E402
 from oracle.unet3d_ref import UNet3DConditionModelRef, UNet3DConfig, synthetic_state_dict  # noqa: E402
+from oracle import vae_ref  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TINY = dict(ch=(64, 128, 128, 128), cross=128, in_heads=2)
@@ -79,5 +80,29 @@ def main():
                         ranges=np.array(ranges), T=T, H=H, W=W, steps=steps)
 
 
+def vae_main():
+    """AutoencoderKL decode (tiny widths, same topology): fp32 oracle output of seeded latents + the fp16-CPU
+    noise floor of the same computation."""
+    torch.set_num_threads(8)
+    cfg = vae_ref.VaeConfig.tiny()
+    sd16 = {k: v.half() for k, v in vae_ref.synthetic_state_dict(cfg, seed=4321).items()}
+    m32 = vae_ref.AutoencoderKLRef(cfg).eval()
+    m32.load_state_dict({k: v.float() for k, v in sd16.items()})
+    m16 = vae_ref.AutoencoderKLRef(cfg).eval().half()
+    m16.load_state_dict(sd16)
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(3, 4, 8, 16, generator=g).half()          # 3 frames, 8x16 latent -> 64x128 pixels
+    with torch.no_grad():
+        o32 = m32.decode(z.float()).sample
+        o16 = m16.decode(z).sample
+    floor = rel_l2(o16.float(), o32)
+    print(f"vae_tiny: out std {o32.std():.4f} max {o32.abs().max():.3f}  fp16-CPU floor rel-L2 {floor:.3e}")
+    np.savez_compressed(os.path.join(HERE, "vae_tiny.npz"), out=o32.numpy().astype(np.float16), floor=np.float64(floor))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "vae":
+        vae_main()
+    else:
+        main()
+        vae_main()
