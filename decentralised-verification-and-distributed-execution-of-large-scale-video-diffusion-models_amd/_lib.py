@@ -41,7 +41,8 @@ SIGNATURES = {
     "vdx_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
     "vdx_groupnorm_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "vdx_layernorm_f16": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
-    "vdx_flash_attn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "vdx_flash_attn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "vdx_gelu_f16": (_i, [_vp, _vp, _sz, _vp]),
     "vdx_temporal_attn_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vdx_cfg_input_f16": (_i, [_vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "vdx_cfg_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),

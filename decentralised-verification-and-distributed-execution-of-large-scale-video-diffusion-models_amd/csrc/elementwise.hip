@@ -88,6 +88,18 @@ extern "C" int vdx_silu_f16(const void* x, void* y, size_t n, vdx_stream_t strea
     return vdx_launch_status("vdx_silu_f16");
 }
 
+// ---- exact GELU (CLIP text tower MLP) ---------------------------------------------------------
+__global__ void gelu_kernel(const f16* x, f16* y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (f16)gelu_erf_f((float)x[i]);
+}
+extern "C" int vdx_gelu_f16(const void* x, void* y, size_t n, vdx_stream_t stream) {
+    VDX_CHECK(x && y && n > 0, "gelu: bad arguments");
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gelu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, n);
+    return vdx_launch_status("vdx_gelu_f16");
+}
+
 // ---- fsdp_chunked_coherent.py:133-137 -------------------------------------------------------
 //   x = cat([lat]*2);  x = x + context_weight * ctx.repeat(1,1,F,1,1)
 __global__ void cfg_input_kernel(const f16* lat, const f16* ctx, float weight, f16* x2, int C, int F, int HW) {

@@ -26,10 +26,12 @@ struct FlashP {
     f16* out;
     int ldq, ldk, ldvt, ldo;
     int sq, skv, skv_pad, seq_per_kv;
+    int causal;   // 1: key j attends only to queries >= j (CLIP text tower); K/V tiles above the block's last query are skipped
     float c;  // scale * log2(e)
 };
 
-template <int QB>
+// CAUSAL is a template parameter: the spatial / cross-attention instantiations carry no trace of the mask
+template <int QB, bool CAUSAL>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     // LDS: 2 stages x { K tile [64 key][64 d], V^T tile [64 d][64 key] }, 128-B rows,
     // 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7)  (conflict-free for both reads)
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 
     bool offset_on = false;                // wave-uniform: some row of this wave has a non-zero offset
     const int krow = pi_row(r32);
-    const int ntiles = (p.skv + 63) >> 6;
+    int ntiles = (p.skv + 63) >> 6;
+    if (CAUSAL) ntiles = min(ntiles, ((int)(blockIdx.x + 1) * 4 * 32 * QB + 63) >> 6);   // keys beyond the block's last query: all masked
     issue(0, 0);
     __syncthreads();                       // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
     for (int t = 0; t < ntiles; ++t) {
@@ -148,6 +151,15 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
                     for (int j = 0; j < 16; ++j)
                         if (k0 + kb * 32 + acc_key(j, h) >= p.skv) s_acc[qb][kb][j] = NEG_BIG;
         }
+        if (CAUSAL && k0 + 63 > q0) {                              // tile reaches past this wave's first query
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (k0 + kb * 32 + acc_key(j, h) > q0 + qb * 32 + r32) s_acc[qb][kb][j] = NEG_BIG;
+        }
         // ---- row maxima.  The offset m is LAZY: it stays 0 (and its MFMA is skipped) while every row
         // maximum of S' lies in (-4, 10] — p = exp2(S') <= 2^10 is exact-enough fp16 with fp32 sums,
         // and >= 2^-4 keeps the small tail out of fp16 subnormals; a row leaving the window is
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) m = fmaxf(m, s_acc[qb][kb][j]);
             mx[qb] = fmaxf(m, __shfl_xor(m, 32, 64));
-            move[qb] = mx[qb] > 10.0f || mx[qb] < -4.0f;
+            move[qb] = mx[qb] > 10.0f || (mx[qb] < -4.0f && (!CAUSAL || mx[qb] > -1.0e29f));   // (causal: a fully masked tile row moves nothing)
             any_move |= move[qb];
         }
         if (__builtin_amdgcn_ballot_w64(any_move) != 0) {            // rare
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 
 extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                                   void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
-                                  int seq_per_kv, float scale, vdx_stream_t stream) {
+                                  int seq_per_kv, float scale, int causal, vdx_stream_t stream) {
     VDX_CHECK(q && k && vt && out, "flash_attn: null pointer");
     VDX_CHECK(n_seq > 0 && sq > 0 && skv > 0 && heads > 0 && seq_per_kv > 0, "flash_attn: empty problem");
     VDX_CHECK(skv_pad >= skv && skv_pad % 8 == 0, "flash_attn: skv_pad=%d must be >= skv=%d and a multiple of 8", skv_pad, skv);
@@ -266,17 +278,20 @@ extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk
     FlashP p;
     p.q = (const f16*)q; p.k = (const f16*)k; p.vt = (const f16*)vt; p.out = (f16*)out;
     p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
-    p.sq = sq; p.skv = skv; p.skv_pad = skv_pad; p.seq_per_kv = seq_per_kv;
+    p.sq = sq; p.skv = skv; p.skv_pad = skv_pad; p.seq_per_kv = seq_per_kv; p.causal = causal ? 1 : 0;
+    VDX_CHECK(!causal || seq_per_kv == 1, "flash_attn: causal masking is for self-attention (seq_per_kv == 1)");
     p.c = scale * 1.44269504088896341f;
     static const int force_qb = getenv("VDX_FLASH_QB") ? atoi(getenv("VDX_FLASH_QB")) : 0;   // tuning knob
     // 64 queries per wave when the sequence is long enough to fill the chip with 256-query blocks
     const bool two = force_qb ? force_qb == 2 : (sq >= 512 && skv >= 256);
     if (two) {
         dim3 grid((sq + 255) / 256, heads, n_seq);
-        hipLaunchKernelGGL(flash_attn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (causal) hipLaunchKernelGGL((flash_attn_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
         dim3 grid((sq + 127) / 128, heads, n_seq);
-        hipLaunchKernelGGL(flash_attn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (causal) hipLaunchKernelGGL((flash_attn_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     return vdx_launch_status("vdx_flash_attn_f16");
 }

@@ -196,6 +196,16 @@ def silu(x, out=None):
     return out
 
 
+def gelu(x, out=None):
+    lib = _lib.load()
+    if not x.is_contiguous():
+        raise VdxError("gelu: x must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.vdx_gelu_f16(_p(x, "x"), _p(out, "out"), x.numel(), _stream()), "vdx_gelu_f16")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 _gn_ws: dict = {}
 
@@ -273,7 +283,7 @@ def rows_to_u8_frames(rows, n, H, W):
 
 
 # --------------------------------------------------------------------------------------------
-def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, out=None):
+def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, out=None, causal=False):
     """q rows [n_seq*sq][>=heads*64]; k rows [n_kv*skv_pad][>=heads*64]; vt [heads*64][>= n_kv*skv_pad]."""
     lib = _lib.load()
     qr, qc, ldq = _rows(q, "q")
@@ -293,7 +303,7 @@ def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, o
     if orow < n_seq * sq or ocol < inner:
         raise VdxError("flash_attn: out too small")
     _lib.check(lib.vdx_flash_attn_f16(_p(q, "q"), ldq, _p(k, "k"), ldk, _p(vt, "vt"), ldvt, _p(out, "out"), ldo,
-                                      n_seq, sq, skv, skv_pad, heads, seq_per_kv, float(scale), _stream()),
+                                      n_seq, sq, skv, skv_pad, heads, seq_per_kv, float(scale), int(bool(causal)), _stream()),
                "vdx_flash_attn_f16")
     return out
 

@@ -80,6 +80,9 @@ int vdx_rows_to_ncfhw_f16(const void* rows, int ld, void* out, int B, int C, int
 /* y = x * sigmoid(x), n elements (TimestepEmbedding act / ResnetBlock2D.nonlinearity(temb)) */
 int vdx_silu_f16(const void* x, void* y, size_t n, vdx_stream_t stream);
 
+/* y = gelu(x) (exact, erf), n elements: CLIPMLP's activation between fc1 and fc2 (hidden_act "gelu") */
+int vdx_gelu_f16(const void* x, void* y, size_t n, vdx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Normalisation (torch.nn.GroupNorm on 4-D and 5-D inputs, torch.nn.LayerNorm).
  * GroupNorm over `rows_per_sample` rows x (C/G) channels per (sample, group):
@@ -109,10 +112,11 @@ int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* bet
  *   k  : fp16 rows [n_kv*skv_pad][ldk]
  *   vt : fp16 [heads*64][ldvt]  V transposed: vt[h*64+d][kvb*skv_pad + key]
  *   kv batch of sequence s is s / seq_per_kv (cross-attn: all frames of a sample share text).
+ *   causal != 0: query i sees keys <= i only (CLIPTextModel's self-attention, fsdp_chunked_coherent.py:102).
  *   out: fp16 rows [n_seq*sq][ldo].                                                            */
 int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                        void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
-                       int seq_per_kv, float scale, vdx_stream_t stream);
+                       int seq_per_kv, float scale, int causal, vdx_stream_t stream);
 
 /* Temporal self-attention of TransformerTemporalModel: sequences run over the
  * F frames of one latent pixel.  qkv: fp16 rows [B*F*HW][ldqkv] = [q | k | v] each heads*64

@@ -10,6 +10,9 @@ may import anything from this package, and only as the checker / the reported
 CPU baseline.  Nothing under the product package imports it; the product path
 raises when the HIP library is missing.
 
+(`vae_ref.py` restates `AutoencoderKL.decode` the same way.  The CLIP text tower needs no restatement: its
+dependency, `transformers`, is installed, and the tests compare against `transformers.CLIPTextModel` directly.)
+
 PARITY UNPINNED at the diffusers boundary: `diffusers` is not installed in the
 build container, is not vendored under /root/reference, and the reference
 holds no test, fixture or golden vector for any UNet / scheduler / blended

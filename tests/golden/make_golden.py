@@ -100,9 +100,43 @@ def vae_main():
     np.savez_compressed(os.path.join(HERE, "vae_tiny.npz"), out=o32.numpy().astype(np.float16), floor=np.float64(floor))
 
 
+def clip_tiny():
+    """Tiny CLIP text tower (same topology as the SD-2.x one: causal, exact GELU, 64-wide heads) built from the
+    REAL dependency, `transformers.CLIPTextModel`, with seeded weights — shared by the generator and the tests."""
+    import transformers
+    cfg = transformers.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3,
+                                      num_attention_heads=2, max_position_embeddings=77, hidden_act="gelu",
+                                      layer_norm_eps=1e-5, projection_dim=64, bos_token_id=0, eos_token_id=2, pad_token_id=1)
+    torch.manual_seed(77)
+    m = transformers.CLIPTextModel(cfg).eval()
+    with torch.no_grad():
+        for k, v in m.state_dict().items():           # transformers' init is tiny (std 0.02): make activations O(1)
+            if v.dtype.is_floating_point and v.dim() == 2 and "embedding" not in k:
+                v.mul_(4.0)
+            if k.endswith("bias"):
+                v.add_(0.05 * torch.randn(v.shape))
+        m.load_state_dict({k: (v.half().float() if v.dtype.is_floating_point else v) for k, v in m.state_dict().items()})
+    ids = torch.randint(3, 1000, (2, 77), generator=torch.Generator().manual_seed(5))
+    ids[:, 0] = 0
+    ids[0, 20:] = 2                                    # a short prompt padded with EOS, like the tokenizer does
+    return m, ids
+
+
+def clip_main():
+    m, ids = clip_tiny()
+    with torch.no_grad():
+        o32 = m(ids)[0]
+        o16 = m.half()(ids)[0]
+    floor = rel_l2(o16.float(), o32)
+    print(f"clip_tiny: out std {o32.std():.4f} max {o32.abs().max():.3f}  fp16-CPU floor rel-L2 {floor:.3e}")
+    np.savez_compressed(os.path.join(HERE, "clip_tiny.npz"), out=o32.numpy(), floor=np.float64(floor))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "vae":
-        vae_main()
-    else:
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("unet", "all"):
         main()
+    if what in ("vae", "all"):
         vae_main()
+    if what in ("clip", "all"):
+        clip_main()
