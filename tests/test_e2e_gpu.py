@@ -1,0 +1,91 @@
+"""-m gpu: the reference's whole `__call__` (fsdp_chunked_coherent.py:96-276) end to end on the HIP path — token ids
+-> CLIP text encoder -> planner / shared noise / context / CFG+DDIM per chunk / gather / ramp blend -> VAE decode ->
+uint8 frames -> boundary metric + CSV row — against the same chain on the CPU built from the oracle pieces (UNet /
+DDIM / pipeline / VAE restatements) and the real `transformers.CLIPTextModel`.  Tiny widths, same topology."""
+import csv
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+transformers = pytest.importorskip("transformers")
+HERE = os.path.dirname(os.path.abspath(__file__))
+TINY = dict(ch=(64, 128, 128, 128), cross=128, in_heads=2)
+
+
+def test_prompt_ids_to_frames_and_metrics(gpu, tmp_path):
+    import vdx  # noqa: F401
+    from vdx import metrics
+    from vdx.clip_text import CLIPTextConfig, CLIPTextModel
+    from vdx.pipeline import DiffuserConfig, DistributedVideoDiffuser
+    from vdx.scheduler import DDIMScheduler
+    from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
+    from vdx.vae import AutoencoderKL, VaeConfig
+    from oracle import vae_ref
+    from oracle.ddim_ref import DDIMSchedulerRef
+    from oracle.pipeline_ref import run_video
+    from oracle.unet3d_ref import UNet3DConditionModelRef, UNet3DConfig as RefCfg, synthetic_state_dict
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+
+    # ---- the three models, HIP and CPU, same fp16-rounded weights ---------------------------------
+    clip_ref, ids = mg.clip_tiny()                                        # hidden 128 = the tiny UNet's cross dim
+    clip = CLIPTextModel(CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3,
+                                        num_attention_heads=2)).load_transformers_state_dict(clip_ref.state_dict(), device=gpu)
+    sd = synthetic_state_dict(RefCfg.tiny(**TINY), seed=1234)
+    unet = UNet3DConditionModel(UNet3DConfig(block_out_channels=TINY["ch"], cross_attention_dim=TINY["cross"],
+                                             transformer_in_heads=TINY["in_heads"])).load_diffusers_state_dict(sd, device=gpu)
+    unet_ref = UNet3DConditionModelRef(RefCfg.tiny(**TINY)).eval()
+    unet_ref.load_state_dict({k: v.half().float() for k, v in sd.items()})
+    vcfg = vae_ref.VaeConfig.tiny()
+    vsd = {k: v.half() for k, v in vae_ref.synthetic_state_dict(vcfg, seed=4321).items()}
+    vae = AutoencoderKL(VaeConfig(block_out_channels=vcfg.block_out_channels)).load_diffusers_state_dict(vsd, device=gpu)
+    vae_cpu = vae_ref.AutoencoderKLRef(vcfg).eval()
+    vae_cpu.load_state_dict({k: v.float() for k, v in vsd.items()})
+
+    # ---- HIP path (reference order: ids[0] = prompt, ids[1] = "" ; :96-103) ---------------------------
+    T, H, W, steps = 10, 32, 32, 3
+    emb = clip(ids.to(gpu))[0]
+    cond, uncond = emb[:1], emb[1:]
+    cfg = DiffuserConfig(num_frames=T, steps=steps, chunk_size=6, overlap=2, height=H * 8, width=W * 8,
+                         mode="hybrid_ctx", device="cuda", noise_device="cpu")
+    d = DistributedVideoDiffuser(cfg, unet, DDIMScheduler(), uncond, cond)
+    lat, info = d()
+    frames = d.decode_frames(lat, vae, batch=4)
+    assert len(frames) == T and frames[0].shape == (H * 8, W * 8, 3) and frames[0].dtype == np.uint8
+
+    # ---- the same chain on the CPU ----------------------------------------------------------------
+    with torch.no_grad():
+        emb_ref = clip_ref(ids)[0].half()
+    lat_ref, (cs, ov, ranges) = run_video(mg.FP32UNetOnHalfIO(unet_ref), DDIMSchedulerRef(), T, 4, H, W, world=1,
+                                          steps=steps, uncond_emb=emb_ref[1:], cond_emb=emb_ref[:1], chunk_size=6,
+                                          overlap=2, mode="hybrid_ctx")
+    frames_ref = vae_ref.frames_from_latents(vae_cpu, lat_ref)
+    assert (info["chunk_size"], info["overlap"], [tuple(r) for r in info["ranges"]]) == (cs, ov, [tuple(r) for r in ranges])
+    err = float((lat.cpu().double() - lat_ref.double()).norm() / lat_ref.double().norm())
+    diff = np.abs(np.stack(frames).astype(np.int32) - np.stack(frames_ref).astype(np.int32))
+    print(f"e2e: latent rel-L2 {err:.3e}; frames |diff| mean {diff.mean():.3f} max {diff.max()} ({(diff <= 2).mean() * 100:.2f} % within 2 levels)")
+    assert err <= 2e-2
+    assert diff.mean() < 0.6 and (diff <= 2).mean() > 0.97
+    # reference quirk carried through the decoder: frames 0 and T-1 both decode the all-zero latent (they sit in
+    # different decode batches here, so they agree to rounding, not to the bit)
+    d0 = np.abs(frames[0].astype(np.int32) - frames[-1].astype(np.int32))
+    assert d0.max() <= 2 and d0.mean() < 0.1
+
+    # ---- result row (:227-276, 313-333) -------------------------------------------------------------
+    ti = metrics.boundary_l1(frames, info["ranges"])
+    ti_ref = metrics.boundary_l1(frames_ref, ranges)
+    assert ti is not None and abs(ti - ti_ref) < 0.5
+    peak, _ = metrics.peak_vram_mb(torch.device(gpu))
+    row = metrics.result_row({**info, "peak_vram_mb": peak, "temp_instab": ti, "flow_err": None}, mode=cfg.mode,
+                             num_frames=T, elapsed_s=1.5)
+    path = str(tmp_path / "results.csv")
+    metrics.append_csv(path, row)
+    rec = next(csv.DictReader(open(path)))
+    assert rec["mode"] == "hybrid_ctx" and int(rec["num_frames"]) == T and int(rec["chunk_size"]) == cs
+    assert float(rec["temp_instab"]) == pytest.approx(ti) and rec["flow_err"] == "" and int(rec["peak_vram_mb"]) > 0
