@@ -172,10 +172,11 @@ def main():
     ops.PROFILE = None
     finite = bool(torch.isfinite(lat.float()).all())
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
-    tt = torch.tensor([dt, peak_gb], device=dev, dtype=torch.float64)
+    free_b, total_b = torch.cuda.mem_get_info(dev)            # device-wide (the reference's pynvml `used`, :41-45,262)
+    tt = torch.tensor([dt, peak_gb, (total_b - free_b) / 2 ** 30], device=dev, dtype=torch.float64)
     if dist_mode:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt, peak_gb = float(tt[0]), float(tt[1])
+    dt, peak_gb, used_gb = float(tt[0]), float(tt[1]), float(tt[2])
 
     if rank == 0:
         tf_step = TFLOP_PER_STEP_24F * F / 24.0
@@ -187,7 +188,8 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu": F, "scheduler": "DDIM-50", "guidance_scale": 7.5},
-            "peak_hbm_gb_per_gpu": round(peak_gb, 3),
+            "frame_steps_per_s": round(total_frames * args.steps / dt, 3),     # useful frames x steps / wall: what scales
+            "peak_hbm_gb_per_gpu": round(peak_gb, 3), "device_used_gb_per_gpu": round(used_gb, 3),
             "path_tflops_per_gpu": round(tf_step * args.steps / dt, 2),
             "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
             "output_finite": finite,
