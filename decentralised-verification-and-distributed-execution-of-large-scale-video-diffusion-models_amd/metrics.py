@@ -12,7 +12,7 @@ import csv
 import datetime
 import os
 import socket
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -17,7 +17,7 @@ checkpoint would load with `strict=True`.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import List, Optional, Tuple
 

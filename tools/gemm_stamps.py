@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import vdx  # noqa: E402,F401
-from vdx import _lib, ops  # noqa: E402
+from vdx import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 raw = ctypes.CDLL(os.environ["VDX_LIB_PATH"])
