@@ -21,11 +21,14 @@
 #include "attn_common.h"
 #include <stdlib.h>
 
+
 struct FlashP {
     const f16 *q, *k, *vt;
     f16* out;
     int ldq, ldk, ldvt, ldo;
-    int sq, skv, skv_pad, seq_per_kv;
+    int sq, skv, skv_pad, seq_per_kv, heads;
+    int xcd;           // XCD-aware block order in use (npairs % 8 == 0)
+    int nqb, npairs;   // query blocks per (sequence, head) pair; pairs = n_seq * heads  (1-D grid of nqb * npairs blocks)
     int causal;   // 1: key j attends only to queries >= j (CLIP text tower); K/V tiles above the block's last query are skipped
     float c;  // scale * log2(e)
 };
@@ -38,9 +41,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, seq = blockIdx.z;
+    // 1-D grid, XCD-aware: blocks L and L+8 share an XCD (and its L2).  All query blocks of one (sequence, head)
+    // pair read the same K / V^T (2.4 MB at 9216 keys), so a pair's blocks are given to ONE XCD (pair = xcd mod 8)
+    // when the pair count divides by 8: its K/V then come from HBM once instead of once per XCD.
+    int pair, qblk;
+    if (p.xcd) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pair = (slot / p.nqb) * 8 + xcd;
+        qblk = slot % p.nqb;
+    } else {
+        pair = blockIdx.x / p.nqb;
+        qblk = blockIdx.x % p.nqb;
+    }
+    const int head = pair % p.heads, seq = pair / p.heads;
     const int kvb = seq / p.seq_per_kv;
-    const int q0 = (blockIdx.x * 4 + wave) * (32 * QB);
+    const int q0 = (qblk * 4 + wave) * (32 * QB);
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane = query column, pre-scaled --------------
     f16x8 qf[QB][4];
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     bool offset_on = false;                // wave-uniform: some row of this wave has a non-zero offset
     const int krow = pi_row(r32);
     int ntiles = (p.skv + 63) >> 6;
-    if (CAUSAL) ntiles = min(ntiles, ((int)(blockIdx.x + 1) * 4 * 32 * QB + 63) >> 6);   // keys beyond the block's last query: all masked
+    if (CAUSAL) ntiles = min(ntiles, ((qblk + 1) * 4 * 32 * QB + 63) >> 6);   // keys beyond the block's last query: all masked
     issue(0, 0);
     __syncthreads();                       // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
     for (int t = 0; t < ntiles; ++t) {
@@ -284,12 +299,18 @@ extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk
     static const int force_qb = getenv("VDX_FLASH_QB") ? atoi(getenv("VDX_FLASH_QB")) : 0;   // tuning knob
     // 64 queries per wave when the sequence is long enough to fill the chip with 256-query blocks
     const bool two = force_qb ? force_qb == 2 : (sq >= 512 && skv >= 256);
+    p.heads = heads;
+    p.npairs = n_seq * heads;
+    static const bool no_xcd = getenv("VDX_FLASH_NO_XCD") != nullptr;   // A/B knob
+    p.xcd = (p.npairs % 8 == 0 && !no_xcd) ? 1 : 0;
+    p.nqb = two ? (sq + 255) / 256 : (sq + 127) / 128;
+    VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
     if (two) {
-        dim3 grid((sq + 255) / 256, heads, n_seq);
+        dim3 grid(p.nqb * p.npairs);
         if (causal) hipLaunchKernelGGL((flash_attn_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((flash_attn_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        dim3 grid((sq + 127) / 128, heads, n_seq);
+        dim3 grid(p.nqb * p.npairs);
         if (causal) hipLaunchKernelGGL((flash_attn_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((flash_attn_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
