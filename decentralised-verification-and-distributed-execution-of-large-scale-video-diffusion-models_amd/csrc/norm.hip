@@ -219,6 +219,79 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, int ldx, c
     }
 }
 
+// Packed variant for the level-0/1 widths (C = 320 / 640: 40 / 80 vectors of 8 per row): a wave takes
+// R = 8 / 4 rows = 320 vectors = five fully used 1 KB wave loads instead of one row on 40 of its 64 lanes
+// (the one-wave-per-row kernel reaches 3.7 TB/s at C = 320).  Flat vector v = 64*j + lane belongs to row v / nvec;
+// the per-row sums are R wave reductions of masked partials — the same number of reductions per row as before.
+template <int R>
+__global__ __launch_bounds__(256) void layernorm_packed_kernel(const f16* x, int ldx, const f16* gamma, const f16* beta,
+                                                                float eps, int M, int C, f16* y, int ldy) {
+    constexpr int NL = 5;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= M) return;
+    const int nvec = C >> 3;           // R * nvec == 320
+    f16x8 v[NL];
+    int rr[NL], cc[NL];
+    float s[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int flat = 64 * j + lane;
+        rr[j] = flat / nvec;
+        cc[j] = flat - rr[j] * nvec;
+        const bool ok = row0 + rr[j] < M;
+        s[j] = 0.f;
+        if (ok) {
+            v[j] = *(const f16x8*)(x + (size_t)(row0 + rr[j]) * ldx + cc[j] * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[j] += (float)v[j][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = (f16)0.f;
+        }
+    }
+    float mean[NL], rstd[NL];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) t += rr[j] == r ? s[j] : 0.f;
+        const float m = wave_sum(t) / (float)C;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) mean[j] = rr[j] == r ? m : mean[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = (float)v[j][e] - mean[j];
+            q += d * d;
+        }
+        s[j] = q;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) t += rr[j] == r ? s[j] : 0.f;
+        const float rs = rsqrtf(wave_sum(t) / (float)C + eps);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) rstd[j] = rr[j] == r ? rs : rstd[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        if (row0 + rr[j] < M) {
+            const f16x8 g = *(const f16x8*)(gamma + cc[j] * 8);
+            const f16x8 b = *(const f16x8*)(beta + cc[j] * 8);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)v[j][e] - mean[j]) * rstd[j] * (float)g[e] + (float)b[e]);
+            *(f16x8*)(y + (size_t)(row0 + rr[j]) * ldy + cc[j] * 8) = o;
+        }
+    }
+}
+
 extern "C" int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps,
                                  int M, int C, void* y, int ldy, vdx_stream_t stream) {
     VDX_CHECK(x && gamma && beta && y, "layernorm: null pointer");
@@ -226,6 +299,15 @@ extern "C" int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, cons
     const int nv = (C / 8 + 63) / 64;
     VDX_CHECK(nv <= 4, "layernorm: C=%d too wide (max 2048)", C);
     hipStream_t st = (hipStream_t)stream;
+    if (C == 320 || C == 640) {       // packed: R rows per wave, 4 waves per block (measured: 3.75 -> 4.0 TB/s at 320; no gain at 1280)
+        const int R = 2560 / C;
+        dim3 pgrid((M + 4 * R - 1) / (4 * R)), pblock(256);
+#define LNP_LAUNCH(RR) hipLaunchKernelGGL(layernorm_packed_kernel<RR>, pgrid, pblock, 0, st, (const f16*)x, ldx, (const f16*)gamma, (const f16*)beta, eps, M, C, (f16*)y, ldy)
+        if (R == 8) LNP_LAUNCH(8);
+        else LNP_LAUNCH(4);
+#undef LNP_LAUNCH
+        return vdx_launch_status("vdx_layernorm_f16");
+    }
     dim3 grid((M + 3) / 4), block(256);
 #define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, (const f16*)x, ldx, (const f16*)gamma, (const f16*)beta, eps, M, C, (f16*)y, ldy)
     switch (nv) {

@@ -254,7 +254,7 @@ def test_groupnorm(gpu, ns, rps, c1, c2, G, silu):
     close(out, ref, tol=4e-3)
 
 
-@pytest.mark.parametrize("M,C", [(37, 64), (100, 320), (9, 1280), (5, 512)])
+@pytest.mark.parametrize("M,C", [(37, 64), (100, 320), (9, 1280), (5, 512), (4099, 320), (131, 640), (64, 1280)])
 def test_layernorm(gpu, M, C):
     ops, _ = _ops()
     g = torch.Generator().manual_seed(M + C)
