@@ -308,10 +308,14 @@ class UNet3DConditionModel(nn.Module):
                          tconv=(F, S), residual=x if i == 4 else None)
         return y
 
+    # Temporaries are released as soon as their consumer has been enqueued (`del`): kernels run in stream order,
+    # so the caching allocator can hand the block to the next op.  Left to Python scoping, every intermediate of
+    # a transformer block lived until the block returned: 5.6 GB of activations at the 24-frame peak instead of 3.
     def _ff(self, b, t, M):
         W = self.W
         ln = ops.layernorm(t, W[b + ".norm3.weight"], W[b + ".norm3.bias"], M=M)
         gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=M, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
+        del ln
         return ops.gemm(gg, W[b + ".ff.net.2.weight"], M=M, bias=W[b + ".ff.net.2.bias"], residual=t)
 
     def _spatial_transformer(self, p, x, ehs_pad, n_img, F, hh, ww):
@@ -326,6 +330,7 @@ class UNet3DConditionModel(nn.Module):
         n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=n_img,
                           rows_per_sample=S, eps=1e-6, silu_act=False)
         t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
+        del n
         # --- self-attention
         Mp = ops.round_up(M, 64)
         ln = torch.empty((Mp, C), dtype=torch.float16, device=x.device)
@@ -334,18 +339,24 @@ class UNet3DConditionModel(nn.Module):
         ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
         qk = ops.gemm(ln, W[b + ".attn1.to_qk.weight"], M=M)
         vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln, M=C)                       # V^T [C][Mp]
+        del ln
         o = ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_img, sq=S, skv=S, skv_pad=S, heads=heads,
                            seq_per_kv=1, scale=scale)
+        del qk, vt
         t = ops.gemm(o, W[b + ".attn1.to_out.0.weight"], M=M, bias=W[b + ".attn1.to_out.0.bias"], residual=t)
+        del o
         # --- cross-attention over the (padded) text tokens; all F frames of a sample share K/V
         ln = ops.layernorm(t, W[b + ".norm2.weight"], W[b + ".norm2.bias"], M=M)
         q = ops.gemm(ln, W[b + ".attn2.to_q.weight"], M=M)
+        del ln
         nb = ehs_pad.shape[0] // TEXT_PAD
         k = ops.gemm(ehs_pad, W[b + ".attn2.to_k.weight"], M=ehs_pad.shape[0])
         vt = ops.gemm(W[b + ".attn2.to_v.weight"], ehs_pad, M=C)                  # [C][nb*TEXT_PAD]
         o = ops.flash_attn(q, k, vt, n_seq=n_img, sq=S, skv=self._text_len, skv_pad=TEXT_PAD, heads=heads,
                            seq_per_kv=n_img // nb, scale=scale)
+        del q
         t = ops.gemm(o, W[b + ".attn2.to_out.0.weight"], M=M, bias=W[b + ".attn2.to_out.0.bias"], residual=t)
+        del o
         t = self._ff(b, t, M)
         return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
 
@@ -357,11 +368,15 @@ class UNet3DConditionModel(nn.Module):
         n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=B,
                           rows_per_sample=F * S, eps=1e-6, silu_act=False)
         t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
+        del n
         for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
             ln = ops.layernorm(t, W[f"{b}.{nm}.weight"], W[f"{b}.{nm}.bias"], M=M)
             qkv = ops.gemm(ln, W[f"{b}.{a}.to_qkv.weight"], M=M)
+            del ln
             o = ops.temporal_attn(qkv, B=B, F=F, HW=S, heads=heads, scale=scale)
+            del qkv
             t = ops.gemm(o, W[f"{b}.{a}.to_out.0.weight"], M=M, bias=W[f"{b}.{a}.to_out.0.bias"], residual=t)
+            del o
         t = self._ff(b, t, M)
         return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
 
