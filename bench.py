@@ -70,7 +70,7 @@ def cpu_baseline(frames: int, threads: int):
     dt = time.time() - t0
     return {"value": round(1.0 / (dt * 24.0 / frames), 6), "unit": "steps/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32 torch-CPU UNet3D, XL widths, 1 CFG forward at {frames} of 24 frames @576x1024 "
-                      f"({dt:.1f} s), scaled x{24 // frames} to the 24-frame step"}
+                      f"({dt:.1f} s), scaled x{24 / frames:g} to the 24-frame step"}
 
 
 def main():
@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=24, help="frames per chunk (default: BASELINE 24)")
-    ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=2,
+                    help="frames of the bounded CPU-baseline sample (0 = skip); 2 frames = ~13 s on 16 cores")
     ap.add_argument("--shapes", type=int, default=0, help="also list the top-N GEMM shapes by time (dev aid)")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="N=1 only: run the multi-GPU code path (RCCL init, sharded weights, collectives) with world 1")
