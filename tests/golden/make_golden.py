@@ -80,6 +80,30 @@ def main():
                         ranges=np.array(ranges), T=T, H=H, W=W, steps=steps)
 
 
+def xl_inputs():
+    g = torch.Generator().manual_seed(31)
+    sample = torch.randn(2, 4, 4, 32, 64, generator=g).half()          # CFG batch 2, 4 frames, 32x64 latent
+    ehs = torch.randn(2, 77, 1024, generator=g).half()
+    return sample, ehs
+
+
+def unet_xl_main():
+    """The FULL-WIDTH UNet (Zeroscope-XL configuration, 1.41 B seeded parameters) at a reduced extent: 4 frames of a
+    32x64 latent give 16384 rows at level 0 — enough for the product to take its full-size kernel choices
+    (weights-stationary GEMMs, 64-query flash blocks).  fp32 oracle output, stored as fp16."""
+    torch.set_num_threads(8)
+    cfg = UNet3DConfig.zeroscope()
+    sd = {k: v.half().float() for k, v in synthetic_state_dict(cfg, seed=1234).items()}
+    m = UNet3DConditionModelRef(cfg).eval()
+    m.load_state_dict(sd)
+    del sd
+    sample, ehs = xl_inputs()
+    with torch.no_grad():
+        out = m(sample.float(), torch.tensor(501), ehs.float()).sample
+    print(f"unet_xl_small: out std {out.std():.4f} max {out.abs().max():.3f}")
+    np.savez_compressed(os.path.join(HERE, "unet_xl_small.npz"), out=out.numpy().astype(np.float16))
+
+
 def vae_main():
     """AutoencoderKL decode (tiny widths, same topology): fp32 oracle output of seeded latents + the fp16-CPU
     noise floor of the same computation."""
@@ -136,6 +160,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("unet", "all"):
         main()
+    if what in ("unet_xl", "all"):
+        unet_xl_main()
     if what in ("vae", "all"):
         vae_main()
     if what in ("clip", "all"):
