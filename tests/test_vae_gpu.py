@@ -90,6 +90,25 @@ def test_vae_tiny_live_oracle_other_shape_and_frames(gpu):
     assert np.array_equal(got, mine)
 
 
+def test_vae_full_width_matches_oracle_live(gpu):
+    """Stable-Diffusion widths (49.5 M seeded parameters) on two frames of a 16x32 latent against the fp32 oracle."""
+    import vdx  # noqa: F401
+    from vdx.vae import AutoencoderKL, VaeConfig
+    from oracle import vae_ref
+    cfg = vae_ref.VaeConfig.sd()
+    sd16 = {k: v.half() for k, v in vae_ref.synthetic_state_dict(cfg, seed=2).items()}
+    ref = vae_ref.AutoencoderKLRef(cfg).eval()
+    ref.load_state_dict({k: v.float() for k, v in sd16.items()})
+    m = AutoencoderKL(VaeConfig.sd()).load_diffusers_state_dict(sd16, device=gpu)
+    z = torch.randn(2, 4, 16, 32, generator=torch.Generator().manual_seed(6)).half()
+    with torch.no_grad():
+        want = ref.decode(z.float()).sample
+    got = m.decode(z.to(gpu)).sample
+    err = rel_l2(got.float().cpu(), want)
+    print(f"vae SD widths, 2 x 16x32: rel-L2 {err:.3e}, out std {float(want.std()):.3f}")
+    assert got.shape == (2, 3, 128, 256) and err <= 4e-3
+
+
 def test_vae_full_width_properties(gpu):
     """Stable-Diffusion widths (512/512/256/128) at a 24x32 latent: finite, deterministic, frames independent of
     their batch neighbours (to rounding), pipeline.decode_frames == decode of the same batch."""
