@@ -12,8 +12,8 @@ the UNet's kernels on channels-last fp16 rows [n*h*w][C]:
     folded weights carry conv_in(bias of post_quant_conv) — zero padding then still pads the *output* of
     post_quant_conv, as in the reference (a plain bias fold would be wrong on the border pixels);
   * ResNet blocks = GroupNorm+SiLU kernels + implicit-GEMM 3x3 convolutions (residual / 1x1 shortcut fused);
-  * mid-block attention (ONE head of 512 channels over h*w tokens): [q|k] GEMM, V^T by the swapped GEMM,
-    scores = one GEMM per image (fp16 [tokens][tokens], as diffusers' baddbmm materialises them), row softmax
+  * mid-block attention (ONE head of 512 channels over h*w tokens): q and k GEMMs, V^T by the swapped GEMM (per
+    image), scores = one GEMM per image (fp16 [tokens][tokens], as diffusers' baddbmm materialises them), row softmax
     kernel (fp32, scale applied in fp32), P.V^T GEMM, output projection with fused residual; the value bias is
     folded into the output projection's bias (softmax rows sum to 1);
   * upsamplers = the conv kernel's fused nearest-x2 gather;
