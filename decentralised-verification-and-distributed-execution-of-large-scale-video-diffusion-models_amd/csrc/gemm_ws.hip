@@ -126,11 +126,13 @@ struct Ws {
         for (int i = 0; i < MT; ++i)   // row = 16*i + frow, so row & 7 == frow & 7
             af[i] = *(const f16x8*)(st + (s >> 1) * SUBT + i * 2048 + ((c ^ (frow & 7)) << 4));
     }
+    // K step 0 starts from the constant 0 (an inline operand of the MFMA): no accumulator clearing
     __device__ __forceinline__ void mfma_step(int s, const f16x8 (&af)[MT], Acc& acc) {
+        const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], af[i], acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], af[i], acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], af[i], s == 0 ? z : acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], af[i], s == 0 ? z : acc[i][1], 0, 0, 0);
         }
     }
     __device__ __forceinline__ void load_res(int k, f16x8 (&rv)[MT]) {
@@ -165,7 +167,7 @@ struct Ws {
         const char* st = smem + (k % NS) * STAGE + frow * 128;
         f16x8 rv[MT];
         if (RES && HAS_PREV) load_res(k - 1, rv);
-        zero(cur);
+        if (!active) zero(cur);
         if (!active) return;
         // (reading the fragments of K step s+1 before the MFMAs of step s was measured: no gain — the other
         // wave(s) of the SIMD already cover the LDS latency)
