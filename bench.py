@@ -31,7 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 TFLOP_PER_STEP_24F = 156.97      # algorithmic FLOPs of one CFG step at 24 f, XL
-PMC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_ws.json")
+PMC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_round_end.json")
 
 
 def pmc_traffic(kernel):
