@@ -162,7 +162,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int frow = lane & 15, fq = lane >> 4;
     const int nk = p.K >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+    int mt_, nt_;
+    gemm_tile_of(bid, p.ntm, p.ntn, mt_, nt_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
     const bool does_a = !SPLIT || wave < 4, does_w = !SPLIT || wave >= 4;
 
     float2* gelu = (float2*)(smem + 2 * STAGE);    // GEGLU: table behind the stage buffers (first barrier publishes it)
@@ -262,6 +264,7 @@ static int launch(const GemmP& p, hipStream_t st) {
     GemmP q = p;
     q.ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;
+    q.ntm = ntm;
     hipLaunchKernelGGL(kern, dim3(ntm * q.ntn), dim3(WM * WN * 64), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16");
 }
@@ -324,7 +327,7 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
     p.frames = a->frames; p.hw = a->hw; p.rpb2 = a->rows_per_bias2 > 0 ? a->rows_per_bias2 : 1;
     p.ldb2 = a->ldb2 > 0 ? a->ldb2 : a->N;
     VDX_CHECK(p.ldb2 % 8 == 0, "gemm: ldb2 must be a multiple of 8");
-    p.ntn = 0;
+    p.ntn = 0; p.ntm = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool geglu = (a->epilogue & VDX_EPI_GEGLU) != 0;
     const int force = (a->epilogue >> 8) & 15;   // kernel variant override (0 = automatic)

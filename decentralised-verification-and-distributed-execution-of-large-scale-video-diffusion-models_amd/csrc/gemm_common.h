@@ -9,7 +9,7 @@ struct GemmP {
     int lda, lda2, ldo, ldr;
     int h_in, w_in, h_out, w_out, stride, ups;
     int frames, hw, rpb2, ldb2;
-    int ntn;
+    int ntn, ntm;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -91,6 +91,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TM][T
 // K-step-32 LDS-ring kernels (gemm_ring.hip); mode = VDX_GEMM_*; variant 0 = 256x320 tile with a
 // four-stage ring (one block per CU), variant 1 = 128x320 tile, two stages, two blocks per CU.
 int vdx_gemm_ring_launch(const GemmP& p, int mode, bool geglu, int variant, hipStream_t st);
+
+// Logical tile id -> (m tile, n tile).  Up to 4 column tiles: n fastest (the tiles of a row block share its
+// activations).  More (N >= 1600: the level-2/3 GEGLU and q|k|v layers): column PANELS of 4 n tiles, m-major inside
+// a panel, so the 32 tiles an XCD works on at a time are 8 row blocks x 4 column tiles — 8.5 MB of first-touch
+// bytes instead of 27 MB at K = 1280 — and a panel's weights stay in that XCD's L2 while the rows sweep past
+// (PMC before: 2.6 GB of L2 fills per level-2 GEGLU launch for 0.24 GB of operands, fabric-bound at 4.5 TB/s).
+__device__ __forceinline__ void gemm_tile_of(int bid, int ntm, int ntn, int& mt, int& nt) {
+    if (ntn <= 4) {
+        mt = bid / ntn;
+        nt = bid - mt * ntn;
+        return;
+    }
+    const int per_panel = ntm * 4;
+    const int panel = bid / per_panel, r = bid - panel * per_panel;
+    const int width = min(4, ntn - panel * 4);          // the last panel may be narrower
+    mt = r / width;
+    nt = panel * 4 + (r - mt * width);
+}
 
 // Weights-stationary streaming kernels for short-K Linear layers (gemm_ws.hip): family 0 = shape not covered.
 int vdx_gemm_ws_family(const GemmP& p, int mode, bool geglu);

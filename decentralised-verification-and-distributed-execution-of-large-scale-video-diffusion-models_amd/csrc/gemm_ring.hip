@@ -40,7 +40,9 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+    int mt_, nt_;
+    gemm_tile_of(bid, p.ntm, p.ntn, mt_, nt_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
     float2* gelu = (float2*)(smem + NS * STAGE);   // GEGLU: table behind the ring (the stage barriers publish it)
     if (GEGLU) gelu_tab_init(gelu, tid, NW * 64);
 
@@ -206,6 +208,7 @@ int launch_ring(const GemmP& p, hipStream_t st) {
     GemmP q = p;
     q.ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;
+    q.ntm = ntm;
     hipLaunchKernelGGL(kern, dim3(ntm * q.ntn), dim3(WMB * 128), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16");
 }
