@@ -148,6 +148,21 @@ def test_gemm_weights_stationary(gpu, M, N, K, flags):
     assert torch.equal(out, ops.gemm(a_view, d(w), M=M, bias=bias, residual=res, variant=2))
 
 
+@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("M,N", [(3000, 1600), (700, 2880), (5000, 4160)])
+def test_gemm_wide_n_panel_order(gpu, variant, M, N):
+    """More than four 320-wide column tiles: tiles are walked in column panels of 4 (gemm_tile_of); 5, 9 and 13 tiles
+    exercise a last panel of width 1; M tails on top."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    K = 128
+    a = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = h(torch.randn(N, generator=g))
+    out = ops.gemm(a.half().to(gpu), w.half().to(gpu), M=M, bias=b.half().to(gpu), variant=variant)
+    close(out, a @ w.t() + b)
+
+
 def test_gemm_two_sources_and_strided_views(gpu):
     ops, _ = _ops()
     g = torch.Generator().manual_seed(5)
