@@ -54,6 +54,20 @@ SIGNATURES = {
 _lib = None
 
 
+def source_sha() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/vdx.h): the identity of the build a profile was
+    taken on.  `.git` does not travel to the GPU box, so profiles/ records this instead of a commit id."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "vdx.h"))
+    for f in files:
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 class VdxError(RuntimeError):
     pass
 

@@ -19,7 +19,6 @@
 // matrix pipe work on one while the VALU exponentiates the other (the kernel is VALU/latency
 // bound at head dim 64, not MFMA bound).
 #include "attn_common.h"
-#include <stdlib.h>
 
 
 struct FlashP {
@@ -108,11 +107,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     };
 
     f32x16 o_acc[QB][2];
-    float m_run[QB], l_run[QB];            // offset in use (exp2 units, fp16-representable); my half of the row sum
+    float m_run[QB], r_run[QB], l_run[QB]; // offset in use (exp2 units, fp16-representable); running row maximum relative to it; my half of the row sum
     f16x8 negm[QB], e0;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         m_run[qb] = l_run[qb] = 0.f;
+        r_run[qb] = NEG_BIG;
 #pragma unroll
         for (int j = 0; j < 16; ++j) o_acc[qb][0][j] = o_acc[qb][1][j] = 0.f;
 #pragma unroll
@@ -175,12 +175,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
                     for (int j = 0; j < 16; ++j)
                         if (k0 + kb * 32 + acc_key(j, h) > q0 + qb * 32 + r32) s_acc[qb][kb][j] = NEG_BIG;
         }
-        // ---- row maxima.  The offset m is LAZY: it stays 0 (and its MFMA is skipped) while every row
-        // maximum of S' lies in (-4, 10] — p = exp2(S') <= 2^10 is exact-enough fp16 with fp32 sums,
-        // and >= 2^-4 keeps the small tail out of fp16 subnormals; a row leaving the window is
-        // re-centred to maximum 0 (offset rounded to fp16; only consistency between p and l matters).
-        // Well-scaled attention never leaves the window, so the common tile pays no max bookkeeping.
-        float mx[QB];
+        // ---- row maxima.  The offset m is LAZY and MONOTONE.  r_run is the row's running maximum over all
+        // tiles so far, measured against the offset in use.  The offset stays put (and, while it is 0, its
+        // MFMA is skipped) as long as r_run lies in (-4, 10]: p = exp2(S') <= 2^10 is exact-enough fp16 with
+        // fp32 sums, and a running maximum >= 2^-4 keeps the terms that matter out of fp16 subnormals.  When
+        // r_run leaves the window the offset is re-centred ON THE RUNNING maximum (rounded to fp16; only
+        // consistency between p and l matters), never on the current tile's: after the first unmasked tile
+        // r_run >= -4 always holds, so from then on the offset only RISES (alpha <= 2^-10) and a row moves
+        // at most (score range / 10) times.  The one downward move possible is the first one (first tile all
+        // below -4): nothing has been accumulated yet, so it rescales nothing (alpha = 1) — exp2(-d) would
+        // overflow there for scores below -128 (0 * inf = NaN).  Tiles far below the running maximum simply
+        // underflow to p = 0, as they do in an fp32 softmax.
         bool move[QB], any_move = false;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -189,23 +194,27 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) m = fmaxf(m, s_acc[qb][kb][j]);
-            mx[qb] = fmaxf(m, __shfl_xor(m, 32, 64));
-            move[qb] = mx[qb] > 10.0f || (mx[qb] < -4.0f && (!CAUSAL || mx[qb] > -1.0e29f));   // (causal: a fully masked tile row moves nothing)
+            r_run[qb] = fmaxf(r_run[qb], fmaxf(m, __shfl_xor(m, 32, 64)));
+            move[qb] = r_run[qb] > 10.0f || (r_run[qb] < -4.0f && r_run[qb] > -1.0e29f);   // (all tiles so far masked: nothing to centre on)
             any_move |= move[qb];
         }
         if (__builtin_amdgcn_ballot_w64(any_move) != 0) {            // rare
             bool nonzero = false;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                const float m_new = (float)(f16)(m_run[qb] + (move[qb] ? mx[qb] : 0.f));
+                // the fp16 offset enters the contraction as an MFMA operand: keep it finite (an infinite one
+                // times the zero rows of its k-step would poison every score with NaN)
+                const float tgt = fminf(fmaxf(m_run[qb] + (move[qb] ? r_run[qb] : 0.f), -60000.0f), 60000.0f);
+                const float m_new = (float)(f16)tgt;
                 const float d = m_new - m_run[qb];                   // shift actually applied
                 m_run[qb] = m_new;
+                r_run[qb] -= d;
                 negm[qb][0] = (f16)(h == 0 ? -m_new : 0.f);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) s_acc[qb][kb][j] -= d;
-                const float alpha = __builtin_amdgcn_exp2f(-d);     // |d| is small: finite; O, l may still be 0
+                const float alpha = d > 0.f ? __builtin_amdgcn_exp2f(-d) : 1.0f;   // d < 0: first move, O = l = 0
                 l_run[qb] *= alpha;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -296,13 +305,11 @@ extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk
     p.sq = sq; p.skv = skv; p.skv_pad = skv_pad; p.seq_per_kv = seq_per_kv; p.causal = causal ? 1 : 0;
     VDX_CHECK(!causal || seq_per_kv == 1, "flash_attn: causal masking is for self-attention (seq_per_kv == 1)");
     p.c = scale * 1.44269504088896341f;
-    static const int force_qb = getenv("VDX_FLASH_QB") ? atoi(getenv("VDX_FLASH_QB")) : 0;   // tuning knob
     // 64 queries per wave when the sequence is long enough to fill the chip with 256-query blocks
-    const bool two = force_qb ? force_qb == 2 : (sq >= 512 && skv >= 256);
+    const bool two = sq >= 512 && skv >= 256;
     p.heads = heads;
     p.npairs = n_seq * heads;
-    static const bool no_xcd = getenv("VDX_FLASH_NO_XCD") != nullptr;   // A/B knob
-    p.xcd = (p.npairs % 8 == 0 && !no_xcd) ? 1 : 0;
+    p.xcd = p.npairs % 8 == 0 ? 1 : 0;
     p.nqb = two ? (sq + 255) / 256 : (sq + 127) / 128;
     VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
     if (two) {

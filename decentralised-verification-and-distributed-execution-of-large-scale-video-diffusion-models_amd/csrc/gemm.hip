@@ -255,12 +255,9 @@ template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT = fal
 static int launch(const GemmP& p, hipStream_t st) {
     constexpr int lds = 2 * (BM + BN) * 128 + (GEGLU ? GELU_TAB_BYTES : 0);
     auto kern = gemm_kernel<BM, BN, WM, WN, MODE, GEGLU, SPLIT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
-        attr_set = true;
-    }
+    // one-time LDS opt-in; a function-local static is initialised exactly once even under concurrent callers
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
     GemmP q = p;
     q.ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;

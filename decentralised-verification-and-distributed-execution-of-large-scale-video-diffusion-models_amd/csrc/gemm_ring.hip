@@ -199,12 +199,9 @@ int launch_ring(const GemmP& p, hipStream_t st) {
     constexpr int BM = WMB * 64;
     constexpr int lds = NS * (BM + BN) * 64 + (GEGLU ? GELU_TAB_BYTES : 0);
     auto kern = gemm_ring_kernel<WMB, NS, MODE, GEGLU>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
-        attr_set = true;
-    }
+    // one-time LDS opt-in; a function-local static is initialised exactly once even under concurrent callers
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
     GemmP q = p;
     q.ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;

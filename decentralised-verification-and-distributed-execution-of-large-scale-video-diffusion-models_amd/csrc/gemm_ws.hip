@@ -277,12 +277,9 @@ int launch_ws(const GemmP& p, hipStream_t st) {
     typedef Ws<K, NW, ROWS, GEGLU, RES, PIPE> W;
     constexpr int lds = W::NS * W::STAGE + (GEGLU ? GELU_TAB_BYTES : 0);
     auto kern = gemm_ws_kernel<K, NW, ROWS, GEGLU, RES, PIPE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return vdx_fail("gemm_ws: cannot reserve %d bytes of LDS", lds);
-        attr_set = true;
-    }
+    // one-time LDS opt-in; a function-local static is initialised exactly once even under concurrent callers
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_rc != hipSuccess) return vdx_fail("gemm_ws: cannot reserve %d bytes of LDS", lds);
     WsP q;
     q.g = p;
     q.nt = (p.N + 32 * NW - 1) / (32 * NW);

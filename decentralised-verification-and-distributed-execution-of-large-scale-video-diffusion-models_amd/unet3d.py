@@ -324,8 +324,6 @@ class UNet3DConditionModel(nn.Module):
         C = x.shape[1]
         heads = C // 64
         scale = 64 ** -0.5
-        if S % 8 != 0:
-            raise VdxError(f"spatial attention needs h*w % 8 == 0 at every level (got {hh}x{ww})")
         b = p + ".transformer_blocks.0"
         n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=n_img,
                           rows_per_sample=S, eps=1e-6, silu_act=False)
@@ -337,12 +335,31 @@ class UNet3DConditionModel(nn.Module):
         if Mp != M:
             ln[M:].zero_()
         ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
-        qk = ops.gemm(ln, W[b + ".attn1.to_qk.weight"], M=M)
-        vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln, M=C)                       # V^T [C][Mp]
-        del ln
-        o = ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_img, sq=S, skv=S, skv_pad=S, heads=heads,
-                           seq_per_kv=1, scale=scale)
-        del qk, vt
+        if S % 8 == 0:
+            qk = ops.gemm(ln, W[b + ".attn1.to_qk.weight"], M=M)
+            vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln, M=C)                   # V^T [C][Mp]
+            del ln
+            o = ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_img, sq=S, skv=S, skv_pad=S, heads=heads,
+                               seq_per_kv=1, scale=scale)
+            del qk, vt
+        else:
+            # Token counts that are no multiple of 8 (latent 40x72 -> 5x9 = 45 tokens at the mid block,
+            # InferNet/tests/test_pipeline.py:293; 16x16 -> 2x2 = 4, InferNet/neurons/miner.py:491-494): the
+            # attention kernel reads V^T in 16-byte chunks of 8 keys, so every image's keys start at a multiple
+            # of 8 — K and V^T are projected from a copy of the normalised rows laid out with S_pad rows per
+            # image (pad rows zero; the kernel masks keys >= S).  Only the smallest levels ever get here.
+            Sp = ops.round_up(S, 8)
+            Mk = n_img * Sp
+            lnp = torch.zeros((ops.round_up(Mk, 64), C), dtype=torch.float16, device=x.device)
+            lnp[:Mk].view(n_img, Sp, C)[:, :S] = ln[:M].view(n_img, S, C)
+            wqk = W[b + ".attn1.to_qk.weight"]
+            q = ops.gemm(ln, wqk[:C], M=M)
+            k = ops.gemm(lnp, wqk[C:], M=Mk)
+            vt = ops.gemm(W[b + ".attn1.to_v.weight"], lnp, M=C)                  # V^T [C][n_img*Sp (+pad)]
+            del ln, lnp
+            o = ops.flash_attn(q, k, vt, n_seq=n_img, sq=S, skv=S, skv_pad=Sp, heads=heads, seq_per_kv=1,
+                               scale=scale)
+            del q, k, vt
         t = ops.gemm(o, W[b + ".attn1.to_out.0.weight"], M=M, bias=W[b + ".attn1.to_out.0.bias"], residual=t)
         del o
         # --- cross-attention over the (padded) text tokens; all F frames of a sample share K/V
@@ -406,8 +423,8 @@ class UNet3DConditionModel(nn.Module):
         nlev = len(c.block_out_channels)
         if H % (2 ** (nlev - 1)) or Wd % (2 ** (nlev - 1)):
             raise VdxError("latent height/width must be divisible by 8 (explicit upsample_size is not implemented)")
-        if F > 32:
-            raise VdxError("temporal attention kernel handles at most 32 frames per chunk")
+        if F > 128:
+            raise VdxError("temporal attention kernel handles at most 128 frames per chunk")
         sample = sample.to(torch.float16).contiguous()
         ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16)
         if ehs.shape[0] != B or ehs.shape[2] != c.cross_attention_dim or ehs.shape[1] > TEXT_PAD:

@@ -120,7 +120,7 @@ int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const voi
 
 /* Temporal self-attention of TransformerTemporalModel: sequences run over the
  * F frames of one latent pixel.  qkv: fp16 rows [B*F*HW][ldqkv] = [q | k | v] each heads*64
- * wide, row = (b*F + f)*HW + p.  out rows likewise, [ldo] wide.  F <= 32.                      */
+ * wide, row = (b*F + f)*HW + p.  out rows likewise, [ldo] wide.  F <= 128.                     */
 int vdx_temporal_attn_f16(const void* qkv, int ldqkv, void* out, int ldo, int B, int F, int HW,
                           int heads, float scale, vdx_stream_t stream);
 

@@ -104,6 +104,51 @@ def unet_xl_main():
     np.savez_compressed(os.path.join(HERE, "unet_xl_small.npz"), out=out.numpy().astype(np.float16))
 
 
+XL_CHUNK = dict(T=28, H=32, W=64, steps=50, windows=((0, 16), (16, 28)))   # a 16- and a 12-frame chunk (BASELINE cfg4 / cfg5)
+
+
+def xl_chunk_embeddings():
+    g = torch.Generator().manual_seed(41)
+    emb = torch.randn(2, 77, 1024, generator=g).half()
+    return emb[1:], emb[:1]                                             # uncond, cond
+
+
+def unet_xl_chunks_main():
+    """The per-rank workload of BASELINE configs 4 and 5 at a reduced extent: the FULL-WIDTH UNet on a 16-frame and a
+    12-frame chunk of one shared-noise video (32x64 latent), with global-context injection, ONE step of
+    `_denoise` (fsdp_chunked_coherent.py:129-143: cat, + 0.35 ctx, UNet, CFG combine, DDIM step at t = 981).
+    Stored: eps (UNet output on the CFG batch) and the latent after the step, fp16."""
+    from oracle.pipeline_ref import base_noise, global_context, denoise
+    torch.set_num_threads(8)
+    cfg = UNet3DConfig.zeroscope()
+    sd = {k: v.half().float() for k, v in synthetic_state_dict(cfg, seed=1234).items()}
+    m = UNet3DConditionModelRef(cfg).eval()
+    m.load_state_dict(sd)
+    del sd
+    c = XL_CHUNK
+    base = base_noise(c["T"], 4, c["H"], c["W"])
+    ctx = global_context(c["T"], 4, c["H"], c["W"])
+    uncond, cond = xl_chunk_embeddings()
+    out = {}
+
+    class Rec(FP32UNetOnHalfIO):
+        def forward(self, x, t, encoder_hidden_states):
+            o = super().forward(x, t, encoder_hidden_states)
+            self.last = o.sample
+            return o
+
+    u = Rec(m)
+    for s, e in c["windows"]:
+        sched = DDIMSchedulerRef()
+        sched.set_timesteps(c["steps"])
+        sched.timesteps = sched.timesteps[:1]                           # one step, at the first timestep of the 50
+        lat = denoise(u, sched, base[:, :, s:e].clone(), uncond, cond, 7.5, ctx, 0.35)
+        print(f"xl chunk {e - s} f: eps std {u.last.float().std():.4f}  lat std {lat.float().std():.4f}")
+        out[f"eps_{e - s}"] = u.last.numpy()
+        out[f"lat_{e - s}"] = lat.numpy()
+    np.savez_compressed(os.path.join(HERE, "unet_xl_chunks.npz"), **out)
+
+
 def vae_main():
     """AutoencoderKL decode (tiny widths, same topology): fp32 oracle output of seeded latents + the fp16-CPU
     noise floor of the same computation."""
@@ -162,6 +207,8 @@ if __name__ == "__main__":
         main()
     if what in ("unet_xl", "all"):
         unet_xl_main()
+    if what in ("unet_xl_chunks", "all"):
+        unet_xl_chunks_main()
     if what in ("vae", "all"):
         vae_main()
     if what in ("clip", "all"):

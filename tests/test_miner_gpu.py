@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 TINY = dict(ch=(64, 128, 128, 128), cross=128, in_heads=2)
 
 
-def test_miner_loop_trace_is_bit_stable_and_matches_oracle(gpu):
+@pytest.mark.parametrize("shape", [(1, 4, 4, 16, 32),
+                                   (1, 4, 3, 16, 16)])    # the miner's default: 128x128 px, 3 frames (miner.py:491-494,550)
+def test_miner_loop_trace_is_bit_stable_and_matches_oracle(gpu, shape):
     import vdx  # noqa: F401
     from vdx.miner import denoise_with_trace, leaf_hash
     from vdx.scheduler import DDIMScheduler
@@ -22,7 +24,7 @@ def test_miner_loop_trace_is_bit_stable_and_matches_oracle(gpu):
     cfg = UNet3DConfig(block_out_channels=TINY["ch"], cross_attention_dim=TINY["cross"], transformer_in_heads=TINY["in_heads"])
     unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(sd, device=gpu)
     g = torch.Generator().manual_seed(3)
-    z0 = torch.randn(1, 4, 4, 16, 32, generator=g).half()
+    z0 = torch.randn(*shape, generator=g).half()
     emb = torch.randn(1, 77, TINY["cross"], generator=g).half()
     steps = 3
     runs = [denoise_with_trace(unet, DDIMScheduler(), z0.to(gpu), emb.to(gpu), steps) for _ in range(2)]

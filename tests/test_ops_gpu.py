@@ -324,7 +324,9 @@ def test_flash_attention_large_scores_online_rescale(gpu):
     close(out, ref, tol=4e-3)
 
 
-@pytest.mark.parametrize("case", ["all_very_negative", "all_very_positive", "late_spike_up", "drift_down_then_up"])
+@pytest.mark.parametrize("case", ["all_very_negative", "all_very_positive", "late_spike_up", "drift_down_then_up",
+                                  "all_minus_150_nat", "tile0_spike_plus_150_nat", "falling_60_nat_per_tile",
+                                  "rising_60_nat_per_tile", "first_tile_low_then_window"])
 @pytest.mark.parametrize("s", [320, 640])
 def test_flash_attention_lazy_offset_branches(gpu, case, s):
     """The softmax offset is lazy (kept at 0 while row maxima of the scaled scores stay in (-4, 10]).
@@ -345,6 +347,20 @@ def test_flash_attention_lazy_offset_branches(gpu, case, s):
         k = h(k + 9 * u)                       # scaled scores ~ +14: above the window from tile 0
     elif case == "late_spike_up":
         k[s - 20] = h(q.mean(0) * 40 + 3)      # one key far above the window in the last tile
+    elif case in ("all_minus_150_nat", "tile0_spike_plus_150_nat", "falling_60_nat_per_tile",
+                  "rising_60_nat_per_tile", "first_tile_low_then_window"):
+        # Channel 0 carries an exact per-key shift of the scaled score: q[:,0] = 8 (4 on odd rows) and
+        # scale 1/8 make the score of key j move by b[j] (b[j]/2) nat.  Softmax is shift-invariant, so the
+        # fp32 reference stays finite on every one of these; a kernel whose offset can move DOWN by more
+        # than 128 exp2-units (or that rescales 0 by 2^big) returns NaN here (round-1 advisor finding).
+        tile = torch.arange(s) // 64
+        b = {"all_minus_150_nat": torch.full((s,), -150.0),
+             "tile0_spike_plus_150_nat": torch.where(torch.arange(s) == 5, 150.0, 0.0),
+             "falling_60_nat_per_tile": -60.0 * tile,
+             "rising_60_nat_per_tile": 60.0 * tile,
+             "first_tile_low_then_window": torch.where(tile == 0, -40.0, 0.0)}[case]
+        q[:, 0] = torch.where(torch.arange(s) % 2 == 0, 8.0, 4.0)
+        k[:, 0] = b
     else:
         ramp = torch.linspace(-8, 8, s)[:, None]
         q = h(q + 4 * u)
@@ -352,6 +368,7 @@ def test_flash_attention_lazy_offset_branches(gpu, case, s):
     ref = _attn_ref(q[None], k[None], v[None], 1)
     out = ops.flash_attn(q.half().to(gpu), k.half().to(gpu), v.t().contiguous().half().to(gpu), n_seq=1, sq=s,
                          skv=s, skv_pad=s, heads=1, seq_per_kv=1, scale=0.125)
+    assert bool(torch.isfinite(out.float()).all()), "flash attention produced non-finite values"
     close(out, ref, tol=4e-3)
 
 
@@ -375,7 +392,8 @@ def test_flash_cross_attention(gpu, B, Fr, s, heads, skv):
     close(out, ref, tol=4e-3)
 
 
-@pytest.mark.parametrize("B,Fr,HW,heads", [(2, 5, 7, 2), (1, 24, 12, 5), (2, 32, 3, 1), (1, 1, 9, 2), (2, 16, 130, 8)])
+@pytest.mark.parametrize("B,Fr,HW,heads", [(2, 5, 7, 2), (1, 24, 12, 5), (2, 32, 3, 1), (1, 1, 9, 2), (2, 16, 130, 8),
+                                           (1, 33, 5, 2), (2, 48, 6, 1), (1, 96, 3, 2), (1, 128, 2, 1)])
 def test_temporal_attention(gpu, B, Fr, HW, heads):
     ops, _ = _ops()
     g = torch.Generator().manual_seed(B + Fr + HW)

@@ -41,6 +41,11 @@ def main():
     durs, counts = {}, {}
     args = sys.argv[1:]
     json_out = None
+    forwards = 2                    # UNet forwards in the profiled command (bench.py --steps 1 --warmup 1)
+    if "--forwards" in args:
+        i = args.index("--forwards")
+        forwards = int(args[i + 1])
+        del args[i:i + 2]
     if "--json" in args:            # per-kernel HBM bytes per launch, for bench.py's roofline.traffic
         i = args.index("--json")
         json_out = args[i + 1]
@@ -67,8 +72,18 @@ def main():
     tot = sum(r[0] for r in rows)
     if json_out:
         import json
-        json.dump({k: {"launches": n, "hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n,
-                       "mfma_busy": util} for t, k, n, rd, wr, bw, util in rows if n}, open(json_out, "w"), indent=1)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import vdx  # noqa: F401
+        from vdx._lib import source_sha
+        out = {k: {"launches": n, "hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n,
+                   "mfma_busy": util} for t, k, n, rd, wr, bw, util in rows if n}
+        # identity of what was profiled: bench.py reports `roofline.traffic` from this file only when the kernel
+        # sources it runs hash to the same value (a stale profile gives traffic = null, not a wrong number)
+        out["_meta"] = {"source_sha": source_sha(), "forwards": forwards,
+                        "hbm_bytes_all_kernels": sum(rd + wr for t, k, n, rd, wr, bw, util in rows),
+                        "kernels": sorted(k for t, k, n, rd, wr, bw, util in rows if n)}
+        json.dump(out, open(json_out, "w"), indent=1)
     print("| kernel | launches | time share | HBM read GB (x2-corrected) | HBM write GB | HBM GB/s | MFMA busy |")
     print("|---|---|---|---|---|---|---|")
     for t, k, n, rd, wr, bw, util in rows[:32]:
