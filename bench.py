@@ -4,17 +4,20 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* = one iteration of `fsdp_chunked_coherent.py:132-142` for the chunk a rank owns:
-cat/ctx-inject -> UNet3D forward on the CFG batch of 2 -> guidance combine -> DDIM update.
-N=1 : BASELINE config[1] — Zeroscope-XL, 24 frames @ 576x1024 (latent 72x128), monolithic.
-N>1 : weak scaling over frame chunks — a 20*N-frame video planned with chunk 24 / overlap 4 by
-      the reference planner gives exactly N windows, one per rank (round-robin, :149-184): N-1 of
-      24 frames and, as the reference planner always does with an overlap, a shorter last one
-      (20 frames).  UNet parameters are sharded 1/N per GPU (per-unit RCCL all-gather, prefetched on
-      a side stream); no other collective inside the step; ctx broadcast before and chunk gather
-      after the loop are outside the timed steps.
-      value = (frames all ranks denoise per step / 24) * steps / max-over-ranks time,
-      i.e. 24-frame-equivalent steps per second (FLOPs are linear in the frame count).
+A *step* = one iteration of `fsdp_chunked_coherent.py:132-142` for every chunk a rank owns, lock-step
+across ranks: cat/ctx-inject -> UNet3D forward on the CFG batch of 2 -> guidance combine -> DDIM update.
+The workload is the BASELINE.json configuration of the world size (`config.workload` names it):
+  N=1  cfg2: Zeroscope-XL, 24 frames @576x1024 (latent 72x128), monolithic, weights resident.
+  N=2  cfg3: the same 24-frame clip, `--mode fsdp` (fsdp.py:130-153, planner :150-151 + padding :174-177): BOTH ranks
+       denoise the full clip; only parameter memory is saved (1/2 of every unit per GPU, per-unit RCCL all-gather).
+  N=4  cfg4: 48 frames, planner's 4 x 16-frame windows (overlap 4), FSDP + chunked (`hybrid`), one window per GPU.
+  N=8  cfg5: 96 frames, 7 x 16 + 1 x 12-frame windows, `hybrid_ctx` (global-context injection), one window per GPU.
+  other N: 12*N frames through the planner's automatic chunking, `hybrid_ctx`.
+UNet parameters are sharded 1/N per GPU for N > 1 (per-unit all-gather prefetched on a side stream); there is no other
+collective inside a step; ctx broadcast before and the chunk exchange after the loop are outside the timed steps.
+value = (USEFUL frames of the video / 24) * steps / max-over-ranks time: 24-frame-equivalent denoising steps per
+second (FLOPs are linear in the frame count; frames that two windows both compute count once — SURVEY §8d(ii)).
+`lockstep_steps_per_s` is the plain steps / time of the job.
 Weights are synthetic (diffusers-shaped, seeded); inputs are synthetic noise/text embeddings.
 Prints ONE JSON line on rank 0.
 """
@@ -31,19 +34,39 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 TFLOP_PER_STEP_24F = 156.97      # algorithmic FLOPs of one CFG step at 24 f, XL
-PMC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_round_end.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_current.json")
+MONO_PEAKS_JSON = os.path.join(ROOT, "profiles", "monolithic_peaks.json")
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
-    (FETCH_SIZE x2-corrected + WRITE_SIZE, tools/pmc_summary.py --json): counters cannot be read from inside
-    the bench process.  None when the profile does not list the kernel."""
+    """(HBM bytes per launch of `kernel`, HBM bytes per step over all kernels, note) from the committed rocprofv3 PMC
+    passes of this same workload (FETCH_SIZE x2-corrected + WRITE_SIZE, tools/pmc_summary.py --json): counters cannot
+    be read from inside the bench process.  The profile records the hash of the kernel sources it was taken on;
+    when the sources this process runs hash differently (or the kernel is not in the profile) the answer is None —
+    a stale profile must not pass for a measurement of this build."""
     try:
-        import json as _json
-        e = _json.load(open(PMC_JSON)).get(kernel)
-        return round(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]) if e else None
-    except (OSError, ValueError, KeyError):
-        return None
+        from vdx._lib import source_sha
+        prof = json.load(open(PMC_JSON))
+        meta = prof.get("_meta", {})
+        if meta.get("source_sha") != source_sha():
+            return None, None, f"profiles/pmc_current.json was taken on kernel sources {meta.get('source_sha')}, this build is {source_sha()}"
+        e = prof.get(kernel)
+        per_step = meta.get("hbm_bytes_all_kernels", 0) / max(meta.get("forwards", 2), 1)
+        return (round(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]) if e else None,
+                round(per_step) if per_step else None, None if e else "kernel not in the profile")
+    except (OSError, ValueError, KeyError) as ex:
+        return None, None, f"no usable PMC profile: {ex}"
+
+
+def select_config(world, name=None):
+    """BASELINE.json configuration for a world size -> (name, total frames T, mode, description)."""
+    table = {"cfg2": (24, "mono"), "cfg3": (24, "fsdp"), "cfg4": (48, "hybrid"), "cfg5": (96, "hybrid_ctx")}
+    if name is None:
+        name = {1: "cfg2", 2: "cfg3", 4: "cfg4", 8: "cfg5"}.get(world)
+    if name is None:
+        return f"generic-{world}", 12 * world, "hybrid_ctx"
+    T, mode = table[name]
+    return name, T, mode
 
 
 PEAK_MFMA_TFLOPS = 2500.0        # gfx950 dense fp16/bf16 matrix peak (MI355X_MICROARCH.md)
@@ -78,7 +101,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=24, help="frames per chunk (default: BASELINE 24)")
+    ap.add_argument("--frames", type=int, default=0, help="override the total frame count of the configuration (dev aid)")
+    ap.add_argument("--config", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="BASELINE configuration to run (default: the one of the world size)")
+    ap.add_argument("--as-world", type=int, default=0,
+                    help="with --rehearse-dist on one GPU: plan as if the job had this many ranks ...")
+    ap.add_argument("--as-rank", type=int, default=0, help="... and run the windows of this rank")
     ap.add_argument("--cpu-frames", type=int, default=2,
                     help="frames of the bounded CPU-baseline sample (0 = skip); 2 frames = ~13 s on 16 cores")
     ap.add_argument("--shapes", type=int, default=0, help="also list the top-N GEMM shapes by time (dev aid)")
@@ -117,43 +145,49 @@ def main():
     from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
     from vdx.weights import synthetic_state_dict
 
-    F, H, W = args.frames, 72, 128
+    H, W = 72, 128
     cfg = UNet3DConfig.zeroscope()
     unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
     if dist_mode:
-        unet.shard_(rank, world)       # hybrid mode: 1/N of every unit per GPU, per-unit RCCL all-gather
+        unet.shard_(rank, world)       # 1/N of every unit per GPU, per-unit RCCL all-gather
     sched = DDIMScheduler()
     sched.set_timesteps(50, device=dev)
-    if not dist_mode:
-        T, ranges, ctx = F, [(0, F)], None
-        workload = f"Zeroscope_v2_XL UNet3D, {F} frames @576x1024 (latent {H}x{W}), CFG batch 2, monolithic, 1 GPU"
-    else:
-        T = (F - 4) * world
-        cp = plan(T, world, chunk_size=F, overlap=4)
-        ranges = cp.for_rank(rank)
-        if len(cp.ranges) != world or len(ranges) != 1:
-            raise SystemExit(f"planner gave {cp.ranges} for T={T}, world={world}")
-        workload = (f"Zeroscope_v2_XL UNet3D, {T}-frame video as {world} windows (chunk {F}, overlap 4, hybrid_ctx: "
-                    f"{world - 1} x {F} frames + 1 x {F - 4}), one window per GPU, CFG batch 2, UNet parameters "
-                    f"sharded 1/{world} per GPU with per-unit RCCL all-gather prefetch")
+    plan_world, plan_rank = (args.as_world, args.as_rank) if (args.rehearse_dist and args.as_world) else (world, rank)
+    cname, T, mode = select_config(plan_world, args.config)
+    if args.frames:
+        T = args.frames
+    if mode == "mono" and dist_mode:
+        mode = "fsdp"
+    cp = plan(T, plan_world, chunk_size=0, overlap=4, no_chunking=mode in ("mono", "fsdp"))
+    ranges = cp.for_rank(plan_rank)
+    desc = {"mono": "monolithic, weights resident, 1 GPU",
+            "fsdp": f"--mode fsdp: every rank denoises the full clip, UNet parameters sharded 1/{world} per GPU",
+            "hybrid": f"--mode hybrid (FSDP + chunked): windows {list(cp.ranges)} round-robin over {plan_world} ranks, parameters sharded 1/{world}",
+            "hybrid_ctx": f"--mode hybrid_ctx (FSDP + chunked + global-context injection): windows {list(cp.ranges)} round-robin over {plan_world} ranks, parameters sharded 1/{world}"}[mode]
+    workload = (f"BASELINE {cname}: Zeroscope_v2_XL UNet3D, {T} frames @576x1024 (latent {H}x{W}), CFG batch 2, {desc}"
+                + (", per-unit RCCL all-gather prefetch on a side stream" if dist_mode else ""))
     base = seeded_noise((1, 4, T, H, W), sched.init_noise_sigma, dev)
-    if dist_mode:
+    ctx = None
+    if mode == "hybrid_ctx":
         ctx = base.mean(dim=2, keepdim=True).contiguous()
-        dist.broadcast(ctx, src=0)
-    s, e = ranges[0]
-    lat = base[:, :, s:e].clone()
+        if dist_mode:
+            dist.broadcast(ctx, src=0)
+    lats = [base[:, :, s:e].clone() for s, e in ranges]
     torch.manual_seed(1)
     emb = torch.randn(2, 77, 1024, device=dev, dtype=torch.float16)
     ts = sched._host_timesteps
 
-    def step(i, lat):
+    def step(i, lats):
         t = ts[i % len(ts)]
-        x = ops.cfg_input(lat, ctx, 0.35)
-        noise = unet(x, t, encoder_hidden_states=emb).sample
-        return sched.step_cfg(noise, t, lat, 7.5)
+        out = []
+        for lat in lats:
+            x = ops.cfg_input(lat, ctx, 0.35)
+            noise = unet(x, t, encoder_hidden_states=emb).sample
+            out.append(sched.step_cfg(noise, t, lat, 7.5))
+        return out
 
     for i in range(args.warmup):
-        lat = step(i, lat)
+        lats = step(i, lats)
     torch.cuda.reset_peak_memory_stats()
 
     def fence():
@@ -167,11 +201,11 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        lat = step(args.warmup + i, lat)
+        lats = step(args.warmup + i, lats)
     fence()
     dt = time.perf_counter() - t0
     ops.PROFILE = None
-    finite = bool(torch.isfinite(lat.float()).all())
+    finite = all(bool(torch.isfinite(lat.float()).all()) for lat in lats)
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     free_b, total_b = torch.cuda.mem_get_info(dev)            # device-wide (the reference's pynvml `used`, :41-45,262)
     tt = torch.tensor([dt, peak_gb, (total_b - free_b) / 2 ** 30], device=dev, dtype=torch.float64)
@@ -180,17 +214,32 @@ def main():
     dt, peak_gb, used_gb = float(tt[0]), float(tt[1]), float(tt[2])
 
     if rank == 0:
-        tf_step = TFLOP_PER_STEP_24F * F / 24.0
-        total_frames = F if not dist_mode else sum(e_ - s_ for s_, e_ in cp.ranges)
-        sps = (total_frames / F) * args.steps / dt
+        my_frames = sum(e_ - s_ for s_, e_ in ranges)                        # frames THIS rank computes per step
+        computed = sum(e_ - s_ for s_, e_ in cp.ranges)                     # all ranks (overlaps / replicas counted twice)
+        useful = T                                                          # frames of the video
+        if plan_world != world:                                             # one-GPU rehearsal of one rank's share
+            computed, useful = my_frames, my_frames
+        tf_step = TFLOP_PER_STEP_24F * my_frames / 24.0
+        sps = (useful / 24.0) * args.steps / dt
+        try:
+            mono = json.load(open(MONO_PEAKS_JSON)).get(str(T))
+        except (OSError, ValueError):
+            mono = None
         out = {
             "metric": "denoising steps/sec, Zeroscope-XL 24f@1024x576 (CFG UNet3D forward + guidance + DDIM)",
             "value": round(sps, 5), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": workload, "frames_per_gpu": F, "scheduler": "DDIM-50", "guidance_scale": 7.5},
-            "frame_steps_per_s": round(total_frames * args.steps / dt, 3),     # useful frames x steps / wall: what scales
+            "config": {"workload": workload, "baseline_config": cname, "mode": mode, "total_frames": T,
+                       "windows": [list(r) for r in cp.ranges], "frames_rank0": my_frames, "scheduler": "DDIM-50",
+                       "guidance_scale": 7.5},
+            "lockstep_steps_per_s": round(args.steps / dt, 5),                 # plain steps of the job per second
+            "frame_steps_per_s": round(useful * args.steps / dt, 3),          # USEFUL frames x steps / wall: what scales
+            "computed_frame_steps_per_s": round(computed * args.steps / dt, 3),   # incl. overlap frames computed twice
             "peak_hbm_gb_per_gpu": round(peak_gb, 3), "device_used_gb_per_gpu": round(used_gb, 3),
+            # per-device peak against the monolithic single-GPU peak at the SAME total frame count
+            # (profiles/monolithic_peaks.json, measured by tools/mem_profile.py --frames T); north star: <= 0.15 at N = 8
+            "peak_hbm_frac_of_monolithic": round(peak_gb / mono, 4) if mono else None,
             "path_tflops_per_gpu": round(tf_step * args.steps / dt, 2),
             "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
             "output_finite": finite,
@@ -208,10 +257,14 @@ def main():
                     a[2] += 1
             name, (fl, ms, n) = max(agg.items(), key=lambda kv: kv[1][1])
             ach = fl / (ms * 1e-3) / 1e12
+            traffic, step_traffic, note = pmc_traffic(name) if cname == "cfg2" else (None, None, "PMC profile is of cfg2")
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(name), "kernel": name,
+                               "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": name,
                                "launches": n, "avg_launch_ms": round(ms / n, 4),
                                "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}
+            if note:
+                out["roofline"]["traffic_note"] = note
+            out["hbm_traffic_bytes_per_step"] = step_traffic     # sum of PMC read+write over every kernel of one forward
             out["gemm_kernels"] = {k: {"launches": v[2], "ms": round(v[1], 2), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
             out["gemm_ms_per_step"] = round(sum(v[1] for v in agg.values()) / args.steps, 2)
@@ -224,7 +277,7 @@ def main():
             ach = tf_step * args.steps / dt
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None, "kernel": "whole step"}
-        if world == 1 and args.cpu_frames > 0 and not args.rehearse_dist:
+        if world == 1 and args.cpu_frames > 0 and not args.rehearse_dist and cname == "cfg2":
             del unet
             torch.cuda.empty_cache()
             ncpu = min(len(os.sched_getaffinity(0)), 16)      # the 1-GPU box's CPU share

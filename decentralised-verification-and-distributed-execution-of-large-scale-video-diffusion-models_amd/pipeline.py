@@ -5,8 +5,14 @@ Same configuration names as the reference's argparse (`:281-300`): num_frames, s
 guidance_scale, chunk_size, overlap, height, width, mode {fsdp, chunk, hybrid, hybrid_ctx},
 context_weight.  Differences in mechanism (results identical):
   * the per-step arithmetic (ctx injection, CFG combine, DDIM step) runs as two fused kernels;
-  * denoised chunks stay on the device and are exchanged as fixed-shape fp16 tensors with
-    `torch.distributed.all_gather` (RCCL on GPUs) instead of pickled CPU objects;
+  * denoised chunks stay on the device.  Default exchange ("halo"): every frame of the video has ONE owning
+    rank (the rank of the first window that starts at or before it and whose successor starts after it); a
+    rank sends only the frames of its windows that another rank owns — the `overlap` halo frames, 288 KiB per
+    neighbour at XL size — as fixed-shape point-to-point transfers (RCCL send/recv over xGMI, issued on a side
+    HIP stream with event hand-off) and blends and decodes only the frames it owns.  The per-frame accumulation
+    order is the reference's (`for lst in gathered: for s,e,latc in lst`, :208-216), so the owned frames carry
+    exactly the bits of the reference's full blend.  `exchange="allgather"` keeps the reference's
+    everyone-gets-everything semantics (`all_gather_object`, :201) as one fixed-shape `all_gather`;
   * the linear-ramp blend (:204-217) runs on the device, in the reference's accumulation order.
 """
 from __future__ import annotations
@@ -99,6 +105,152 @@ def gather_chunks(mine: List[torch.Tensor], chunk_plan: ChunkPlan, rank: int, wo
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# halo exchange: who owns which frames, who sends what (host logic, integers only)
+# ---------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class HaloTransfer:
+    chunk: int          # window index (position in ChunkPlan.ranges) the frames come from
+    src: int            # rank that denoised it
+    dst: int            # rank that owns the frames
+    s: int              # video frames [s, e)
+    e: int
+
+
+@dataclass(frozen=True)
+class HaloSegment:
+    s: int              # video frames [s, e): all covered by the same set of windows
+    e: int
+    chunks: Tuple[int, ...]     # covering window indices in the REFERENCE's accumulation order
+
+
+class HaloPlan:
+    """Frame ownership and transfers for a ChunkPlan.
+
+    Windows come out of the planner with increasing start frames; the tail may repeat the last window
+    (padding, :174-177) and `--mode fsdp` repeats the only window once per rank.  Distinct windows u = 0.. own the
+    frames [start_u, start_{u+1}) (the last one up to T); the owner rank is the rank of the FIRST window with that
+    range.  Every window (repeats included) that covers frames it does not own on its own rank sends them to the
+    owner.  The reference accumulates `full[s:e] += lat * w` window by window in rank-major order (:208-216); frames
+    are independent in that update, so replaying, per owned frame segment, the covering windows in that same order
+    reproduces the reference's bits."""
+
+    def __init__(self, cp: ChunkPlan, total: int):
+        self.cp, self.total = cp, total
+        W = cp.world
+        n = len(cp.ranges)
+        self.rank_of = [i % W for i in range(n)]
+        self.slot_of = [i // W for i in range(n)]                       # position in the rank's own list
+        # reference accumulation order: rank-major, then the rank's own order (:208-209)
+        self.ref_order = sorted(range(n), key=lambda i: (self.rank_of[i], self.slot_of[i]))
+        pos = {c: k for k, c in enumerate(self.ref_order)}
+        uniq: List[int] = []
+        for i, r in enumerate(cp.ranges):
+            if not uniq or r != cp.ranges[uniq[-1]]:
+                if uniq and r[0] <= cp.ranges[uniq[-1]][0]:
+                    raise ValueError(f"window starts must increase: {cp.ranges}")
+                uniq.append(i)
+        self.owner_chunks = uniq
+        self.owned: dict = {}                                            # rank -> [(s, e)] frames it owns
+        self.segments: dict = {}                                         # rank -> [HaloSegment]
+        self.transfers: List[HaloTransfer] = []
+        for k, i in enumerate(uniq):
+            s0 = cp.ranges[i][0]
+            e0 = cp.ranges[uniq[k + 1]][0] if k + 1 < len(uniq) else total
+            if k == 0:
+                s0 = 0
+            if e0 <= s0:
+                continue
+            owner = self.rank_of[i]
+            self.owned.setdefault(owner, []).append((s0, e0))
+            cover = [j for j, (s, e) in enumerate(cp.ranges) if s < e0 and e > s0]
+            cuts = sorted({s0, e0} | {x for j in cover for x in cp.ranges[j] if s0 < x < e0})
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                cs_ = tuple(sorted((j for j in cover if cp.ranges[j][0] <= a and cp.ranges[j][1] >= b), key=pos.get))
+                self.segments.setdefault(owner, []).append(HaloSegment(a, b, cs_))
+            for j in cover:
+                if self.rank_of[j] != owner:
+                    self.transfers.append(HaloTransfer(j, self.rank_of[j], owner, max(cp.ranges[j][0], s0),
+                                                       min(cp.ranges[j][1], e0)))
+        self.transfers.sort(key=lambda t: (t.chunk, t.s))
+        for r in range(W):
+            self.owned.setdefault(r, [])
+            self.segments.setdefault(r, [])
+
+    def bytes_sent(self, rank: int, frame_bytes: int) -> int:
+        return sum((t.e - t.s) * frame_bytes for t in self.transfers if t.src == rank)
+
+
+def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_stream=None):
+    """Send the frames other ranks own, receive the frames this rank owns from the windows other ranks denoised.
+    Returns ({(chunk, s, e): tensor (1,C,e-s,H,W)}, event or None): the received pieces are valid on the current
+    stream after `event.wait()` (GPU) or immediately (CPU)."""
+    cp = hp.cp
+    ref = mine[0]
+    _, C, _, H, W = ref.shape
+    got, p2p, keep = {}, [], []
+    for t in hp.transfers:
+        if t.src == rank:
+            s0 = cp.ranges[t.chunk][0]
+            piece = mine[hp.slot_of[t.chunk]][:, :, t.s - s0:t.e - s0].contiguous()
+            keep.append(piece)
+            p2p.append(dist.P2POp(dist.isend, piece, t.dst))
+        elif t.dst == rank:
+            buf = ref.new_empty((1, C, t.e - t.s, H, W))
+            got[(t.chunk, t.s, t.e)] = buf
+            p2p.append(dist.P2POp(dist.irecv, buf, t.src))
+    if not p2p:
+        return got, None
+    if ref.is_cuda:
+        cur = torch.cuda.current_stream(ref.device)
+        side = side_stream or torch.cuda.Stream(device=ref.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                                   # pieces / buffers exist once `cur` gets here
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            for r in dist.batch_isend_irecv(p2p):
+                r.wait()
+            done = torch.cuda.Event()
+            done.record(side)
+        for t_ in keep + list(got.values()):
+            t_.record_stream(side)
+        return got, done
+    for r in dist.batch_isend_irecv(p2p):
+        r.wait()
+    return got, None
+
+
+def blend_owned(mine: List[torch.Tensor], hp: HaloPlan, got: dict, done, like: torch.Tensor, rank: int):
+    """Blend the frames this rank owns (reference :204-217 restricted to them).  Segments whose covering windows
+    are all local are accumulated while the halo transfers are still in flight; the others after `done`.
+    Returns [(s, e, fp32 latent (1,C,e-s,H,W))] for the owned ranges, in frame order."""
+    cp, ov = hp.cp, hp.cp.overlap
+    out = []
+    for (o_s, o_e) in hp.owned[rank]:
+        n = o_e - o_s
+        full = like.new_zeros((1, like.shape[1], n, like.shape[3], like.shape[4]))
+        weight = torch.zeros(n, dtype=torch.float32, device=like.device)
+        segs = [g for g in hp.segments[rank] if o_s <= g.s and g.e <= o_e]
+        local = lambda g: all(hp.rank_of[c] == rank for c in g.chunks)    # noqa: E731
+        waited = done is None
+        for g in sorted(segs, key=lambda g: (not local(g), g.s)):
+            if not local(g) and not waited:
+                torch.cuda.current_stream(like.device).wait_event(done)
+                waited = True
+            for c in g.chunks:
+                cs_, ce_ = cp.ranges[c]
+                if hp.rank_of[c] == rank:
+                    piece = mine[hp.slot_of[c]][:, :, g.s - cs_:g.e - cs_]
+                else:
+                    key = next(k for k in got if k[0] == c and k[1] <= g.s and g.e <= k[2])
+                    piece = got[key][:, :, g.s - key[1]:g.e - key[1]]
+                w = ramp_weights(ce_ - cs_, ov)[g.s - cs_:g.e - cs_]
+                ops.blend_accumulate(full, weight, piece.contiguous(), w.contiguous().to(like.device),
+                                     g.s - o_s, g.e - o_s)
+        out.append((o_s, o_e, ops.blend_finalize(full, weight)))
+    return out
+
+
 class DistributedVideoDiffuser:
     def __init__(self, cfg: DiffuserConfig, unet, scheduler, uncond_emb, cond_emb):
         self.cfg = cfg
@@ -146,6 +298,9 @@ class DistributedVideoDiffuser:
             ops.blend_accumulate(full, weight, lat.contiguous(), ramp_weights(e - s, ov).to(like.device), s, e)
         return ops.blend_finalize(full, weight)
 
+    def blend_owned(self, mine, hp, got, done, like):
+        return blend_owned(mine, hp, got, done, like, self.rank)
+
     def decode_frames(self, lat: torch.Tensor, vae, batch: int = 8) -> List:
         """Reference :219-225: the blended latent (1,C,T,h,w) -> T uint8 (H,W,3) frames (numpy, host).
         `z/0.18215` is formed in the latent's dtype and cast to fp16 at the VAE boundary (what the reference's
@@ -159,7 +314,14 @@ class DistributedVideoDiffuser:
             frames += [f for f in u8.cpu().numpy()]
         return frames
 
-    def __call__(self):
+    def _sync(self):
+        if torch.device(self.cfg.device).type == "cuda":
+            torch.cuda.synchronize()
+
+    def __call__(self, exchange: str = "allgather"):
+        """exchange="allgather": every rank ends with the whole blended latent (reference semantics, :201-217)
+        -> (lat fp32 (1,C,T,h,w), info).  exchange="halo": a rank ends with the frames it owns
+        -> ([(s, e, lat fp32 (1,C,e-s,h,w))], info) — the same bits, 1/world of the blend and decode work."""
         cfg = self.cfg
         T, H, W = cfg.num_frames, cfg.height // 8, cfg.width // 8
         cp = self.plan()
@@ -169,12 +331,24 @@ class DistributedVideoDiffuser:
         mine = [self.denoise(base[:, :, s:e].clone()) for s, e in cp.for_rank(self.rank)]
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        self._sync()
         denoise_s = time.time() - t0
+        info = {"chunk_size": cp.chunk, "overlap": cp.overlap, "ranges": list(cp.ranges), "world_size": self.world,
+                "num_frames": T, "denoise_s": denoise_s, "exchange": exchange}
         t0 = time.time()
-        chunks = gather_chunks(mine, cp, self.rank, self.world)
-        gather_s = time.time() - t0
-        lat = self.blend(chunks, base, cp.overlap)
-        return lat, {"chunk_size": cp.chunk, "overlap": cp.overlap, "ranges": list(cp.ranges),
-                     "world_size": self.world, "num_frames": T, "denoise_s": denoise_s,
-                     "net_gather_s": gather_s}
+        if exchange == "allgather":
+            chunks = gather_chunks(mine, cp, self.rank, self.world)
+            self._sync()
+            info["net_gather_s"] = time.time() - t0
+            info["network_bytes"] = (self.world - 1) * cp.per_rank * C * cp.chunk * H * W * 2    # received per rank
+            return self.blend(chunks, base, cp.overlap), info
+        if exchange != "halo":
+            raise ValueError(f"unknown exchange {exchange!r}")
+        hp = HaloPlan(cp, T)
+        got, done = exchange_halos(mine, hp, self.rank) if self.world > 1 else ({}, None)
+        owned = self.blend_owned(mine, hp, got, done, base)
+        self._sync()
+        info["net_gather_s"] = time.time() - t0
+        info["network_bytes"] = sum(t.numel() * 2 for t in got.values())
+        info["owned"] = [(s, e) for s, e, _ in owned]
+        return owned, info
