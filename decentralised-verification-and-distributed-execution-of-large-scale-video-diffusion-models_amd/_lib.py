@@ -44,6 +44,10 @@ SIGNATURES = {
     "vdx_flash_attn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "vdx_gelu_f16": (_i, [_vp, _vp, _sz, _vp]),
     "vdx_temporal_attn_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "vdx_temporal_attn_block_supported": (_i, [_i, _i]),
+    "vdx_temporal_attn_block_wqkv_bytes": (_sz, [_i]),
+    "vdx_temporal_attn_block_wo_bytes": (_sz, [_i]),
+    "vdx_temporal_attn_block_f16": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vdx_cfg_input_f16": (_i, [_vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "vdx_cfg_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),
     "vdx_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _sz, _vp]),

@@ -325,6 +325,40 @@ def temporal_attn(qkv, *, B, F, HW, heads, scale, out=None):
     return out
 
 
+def temporal_attn_block_supported(inner: int, F: int) -> bool:
+    return bool(_lib.load().vdx_temporal_attn_block_supported(inner, F))
+
+
+def temporal_attn_block(t, gamma, beta, wqkv_packed, wo_packed, bo, *, B, F, HW, scale, eps=1e-5, out=None):
+    """K7: t + to_out(attention_over_frames(LayerNorm(t))) in one kernel (include/vdx.h)."""
+    lib = _lib.load()
+    r, inner, ldt = _rows(t, "t")
+    M = B * F * HW
+    if r < M:
+        raise VdxError(f"temporal_attn_block: t has {r} rows, need {M}")
+    if not lib.vdx_temporal_attn_block_supported(inner, F):
+        raise VdxError(f"temporal_attn_block: inner={inner}, F={F} not supported by the fused kernel")
+    if gamma.numel() != inner or beta.numel() != inner or bo.numel() != inner:
+        raise VdxError("temporal_attn_block: gamma/beta/bias size")
+    if wqkv_packed.numel() * 2 != lib.vdx_temporal_attn_block_wqkv_bytes(inner) or \
+            wo_packed.numel() * 2 != lib.vdx_temporal_attn_block_wo_bytes(inner):
+        raise VdxError("temporal_attn_block: packed weight size does not match the kernel's stage layout")
+    if not (wqkv_packed.is_contiguous() and wo_packed.is_contiguous()):
+        raise VdxError("temporal_attn_block: packed weights must be contiguous")
+    if out is None:
+        out = torch.empty((M, inner), dtype=torch.float16, device=t.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < inner:
+        raise VdxError("temporal_attn_block: out too small")
+    if out.data_ptr() == t.data_ptr():
+        raise VdxError("temporal_attn_block: out may not alias t")
+    _lib.check(lib.vdx_temporal_attn_block_f16(_p(t, "t"), ldt, _p(gamma, "gamma"), _p(beta, "beta"), float(eps),
+                                               _p(wqkv_packed, "wqkv"), _p(wo_packed, "wo"), _p(bo, "bo"),
+                                               _p(out, "out"), ldo, B, F, HW, inner, float(scale), _stream()),
+               "vdx_temporal_attn_block_f16")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 def cfg_input(lat, ctx, weight, out=None):
     """fsdp_chunked_coherent.py:133-137: cat([lat]*2) (+ weight * ctx.repeat(F))."""

@@ -83,3 +83,58 @@ def nchw_to_rows(x: torch.Tensor) -> torch.Tensor:
 
 def rows_to_nchw(r: torch.Tensor, n: int, h: int, w: int) -> torch.Tensor:
     return r.reshape(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# K7 (csrc/tattn_fused.hip): weight STAGE IMAGES of the fused temporal-attention sub-block.
+# A stage is what one LDS-DMA burst copies verbatim into one ring slot: [tiles][16 rows][4 slots][8 k]
+# (64-byte rows: the 32 k values of one MFMA k-step); slot s of row n holds k-chunk s ^ g(n >> 2),
+# g = [0, 2, 3, 1], which makes every 16-lane group of the fragment's ds_read_b128 hit 16 distinct
+# 16-byte slots of the 256-byte bank row.
+# ---------------------------------------------------------------------------------------------
+K7_GEOMETRY = {320: dict(nch=1, cg=10), 512: dict(nch=2, cg=8)}      # inner -> column halves, P3 tiles per column group
+_K7_G = (0, 2, 3, 1)
+
+
+def _k7_slot_swizzle(x: torch.Tensor) -> torch.Tensor:
+    """x[..., 16 rows, 4 k-chunks, 8] -> same shape with slot s of row n = chunk s ^ g(n >> 2)."""
+    n = torch.arange(16, device=x.device)
+    g = torch.tensor(_K7_G, device=x.device)[n >> 2]
+    idx = torch.arange(4, device=x.device)[None, :] ^ g[:, None]              # [16][4]: source chunk of slot s
+    idx = idx[..., None].expand(16, 4, 8)
+    return torch.gather(x, -2, idx.expand(x.shape))
+
+
+def pack_k7_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
+    """to_q / to_k / to_v weights [inner][inner] -> stages [head group][k step] of [nch][12 tiles][16][4][8]:
+    tiles 0-3 = the head's q rows (16 per tile), 4-7 = k, 8-11 = v."""
+    inner = wq.shape[0]
+    nch = K7_GEOMETRY[inner]["nch"]
+    heads, ks = inner // 64, inner // 32
+    w = torch.stack([m.reshape(heads, 64, inner) for m in (wq, wk, wv)], dim=1)     # [heads][3][64][inner]
+    w = w.reshape(heads // nch, nch, 12, 16, ks, 4, 8)                               # [hg][ch][tile][n][ks][chunk][8]
+    w = w.permute(0, 4, 1, 2, 3, 5, 6)                                               # [hg][ks][ch][tile][n][chunk][8]
+    return _k7_slot_swizzle(w).contiguous().reshape(-1)
+
+
+def pack_k7_out(wo: torch.Tensor) -> torch.Tensor:
+    """to_out.0 weight [inner][inner] -> stages [column group][k step] of [nch][cg tiles][16][4][8], zero padded to
+    the q|k|v stage size.  Row n of tile (2a + j) of a wave's column group carries output column
+    32a + 8*(n >> 2) + 4j + (n & 3): after the MFMA a lane owns 8 consecutive columns (16-byte stores)."""
+    inner = wo.shape[0]
+    nch, cg = K7_GEOMETRY[inner]["nch"], K7_GEOMETRY[inner]["cg"]
+    ks, wcols = inner // 32, inner // nch
+    ncg = wcols // (16 * cg)
+    dev = wo.device
+    tile = torch.arange(cg, device=dev)[:, None]
+    n = torch.arange(16, device=dev)[None, :]
+    col_in_group = 32 * (tile // 2) + 8 * (n >> 2) + 4 * (tile % 2) + (n & 3)      # [cg][16]
+    chv = torch.arange(nch, device=dev)[None, :, None, None]
+    cgv = torch.arange(ncg, device=dev)[:, None, None, None]
+    col = chv * wcols + cgv * 16 * cg + col_in_group[None, None]                   # [ncg][nch][cg][16]
+    w = wo[col.reshape(-1)].reshape(ncg, nch, cg, 16, ks, 4, 8)
+    w = _k7_slot_swizzle(w.permute(0, 4, 1, 2, 3, 5, 6)).contiguous()              # [ncg][ks][nch][cg][16][4][8]
+    stage = nch * 192 * 32                                                           # elements of a q|k|v stage
+    out = wo.new_zeros((ncg, ks, stage))
+    out[:, :, :nch * cg * 512] = w.reshape(ncg, ks, -1)
+    return out.reshape(-1)

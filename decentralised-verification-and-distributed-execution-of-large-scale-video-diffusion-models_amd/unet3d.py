@@ -73,6 +73,8 @@ class UNet3DConditionModel(nn.Module):
         self._temb_slices: Dict[str, Tuple[int, int]] = {}
         self._device = torch.device("cpu")
         self.dtype = torch.float16
+        self.ff_block_bytes = None     # memory-lean feed-forward (see _ff); shard_() turns it on
+        self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
 
     # ------------------------------------------------------------------------------------------
     # weights
@@ -115,6 +117,9 @@ class UNet3DConditionModel(nn.Module):
             q, k, v = (packing.pack_conv1x1(get(f"{prefix}.to_{n}.weight")) for n in "qkv")
             if fuse_v:      # temporal attention: one [3*inner][inner] projection
                 put(prefix + ".to_qkv.weight", torch.cat([q, k, v], 0))
+                if q.shape[0] in packing.K7_GEOMETRY:      # widths the fused sub-block kernel (K7) is built for
+                    put(prefix + ".k7_qkv", packing.pack_k7_qkv(q, k, v))
+                    put(prefix + ".k7_out", packing.pack_k7_out(packing.pack_conv1x1(get(f"{prefix}.to_out.0.weight"))))
             else:           # spatial self-attention: [q|k] fused, V issued as the swapped GEMM (-> V^T)
                 put(prefix + ".to_qk.weight", torch.cat([q, k], 0))
                 put(prefix + ".to_v.weight", v)
@@ -270,6 +275,7 @@ class UNet3DConditionModel(nn.Module):
         if not isinstance(self.W, dict):
             raise VdxError("weights are already sharded")
         self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group)
+        self.ff_block_bytes = 128 << 20
         if self._device.type == "cuda":
             torch.cuda.empty_cache()
         return self
@@ -313,10 +319,29 @@ class UNet3DConditionModel(nn.Module):
     # a transformer block lived until the block returned: 5.6 GB of activations at the 24-frame peak instead of 3.
     def _ff(self, b, t, M):
         W = self.W
-        ln = ops.layernorm(t, W[b + ".norm3.weight"], W[b + ".norm3.bias"], M=M)
-        gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=M, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
-        del ln
-        return ops.gemm(gg, W[b + ".ff.net.2.weight"], M=M, bias=W[b + ".ff.net.2.bias"], residual=t)
+        inner = t.shape[1]
+        blk = M
+        if self.ff_block_bytes:
+            # memory-lean mode (set by shard_(): the per-device footprint is what the sharded modes are for): the
+            # GEGLU intermediate [rows][4*inner] is the largest tensor of the forward (1.2 GB at 16 frames in
+            # transformer_in); rows are independent, so the feed-forward runs over row blocks and only one block's
+            # intermediate is alive at a time.  Same kernels, same bits.
+            blk = max(16384, (self.ff_block_bytes // (8 * inner)) // 4096 * 4096)
+        if blk >= M:
+            ln = ops.layernorm(t, W[b + ".norm3.weight"], W[b + ".norm3.bias"], M=M)
+            gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=M, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
+            del ln
+            return ops.gemm(gg, W[b + ".ff.net.2.weight"], M=M, bias=W[b + ".ff.net.2.bias"], residual=t)
+        out = torch.empty_like(t[:M])
+        for r0 in range(0, M, blk):
+            r1 = min(r0 + blk, M)
+            ln = ops.layernorm(t[r0:r1], W[b + ".norm3.weight"], W[b + ".norm3.bias"], M=r1 - r0)
+            gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=r1 - r0, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
+            del ln
+            ops.gemm(gg, W[b + ".ff.net.2.weight"], M=r1 - r0, bias=W[b + ".ff.net.2.bias"], residual=t[r0:r1],
+                     out=out[r0:r1])
+            del gg
+        return out
 
     def _spatial_transformer(self, p, x, ehs_pad, n_img, F, hh, ww):
         W, g = self.W, self.cfg.norm_num_groups
@@ -386,7 +411,12 @@ class UNet3DConditionModel(nn.Module):
                           rows_per_sample=F * S, eps=1e-6, silu_act=False)
         t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
         del n
+        fused = self.fuse_temporal_attention and f"{b}.attn1.k7_qkv" in W and ops.temporal_attn_block_supported(t.shape[1], F)
         for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
+            if fused:      # K7: LayerNorm -> q|k|v -> F x F attention -> to_out + residual in one kernel
+                t = ops.temporal_attn_block(t, W[f"{b}.{nm}.weight"], W[f"{b}.{nm}.bias"], W[f"{b}.{a}.k7_qkv"],
+                                            W[f"{b}.{a}.k7_out"], W[f"{b}.{a}.to_out.0.bias"], B=B, F=F, HW=S, scale=scale)
+                continue
             ln = ops.layernorm(t, W[f"{b}.{nm}.weight"], W[f"{b}.{nm}.bias"], M=M)
             qkv = ops.gemm(ln, W[f"{b}.{a}.to_qkv.weight"], M=M)
             del ln

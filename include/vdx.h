@@ -124,6 +124,23 @@ int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const voi
 int vdx_temporal_attn_f16(const void* qkv, int ldqkv, void* out, int ldo, int B, int F, int HW,
                           int heads, float scale, vdx_stream_t stream);
 
+/* K7 — one attention sub-block of TransformerTemporalModel (`s = s + attn(LN(s))`, both attn1 and the
+ * "double self-attention" attn2) as ONE kernel: LayerNorm -> q|k|v -> softmax over the F frames of each latent pixel
+ * -> P.V -> to_out.0 (+bias) + residual.  Rows are read once and written once (csrc/tattn_fused.hip).
+ *   t, out : fp16 rows [B*F*HW][ld], row = (b*F + f)*HW + p, `inner` columns used; out may not alias t
+ *   gamma, beta : LayerNorm affine [inner];  bo : to_out.0 bias [inner]
+ *   wqkv_packed / wo_packed : weight stage images (vdx/packing.py pack_k7_qkv / pack_k7_out), sizes given by
+ *   vdx_temporal_attn_block_wqkv_bytes / _wo_bytes.
+ * Supported: inner 320 or 512, F a divisor of 48 (vdx_temporal_attn_block_supported); callers use the separate
+ * LayerNorm / GEMM / vdx_temporal_attn_f16 kernels otherwise.                                              */
+int vdx_temporal_attn_block_supported(int inner, int F);
+size_t vdx_temporal_attn_block_wqkv_bytes(int inner);
+size_t vdx_temporal_attn_block_wo_bytes(int inner);
+int vdx_temporal_attn_block_f16(const void* t, int ldt, const void* gamma, const void* beta, float eps,
+                                const void* wqkv_packed, const void* wo_packed, const void* bo,
+                                void* out, int ldo, int B, int F, int HW, int inner, float scale,
+                                vdx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Orchestration ops the reference owns (fsdp_chunked_coherent.py).
  * ---------------------------------------------------------------------------------------- */

@@ -22,9 +22,41 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 0.01 * r["achieved"]
 
 
-def test_pmc_traffic_lookup_reads_the_committed_profile():
+def test_pmc_traffic_is_reported_only_for_the_build_that_was_profiled(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a committed PMC profile; a profile taken on other kernel sources must give
+    None (with a note), never a stale number (round-1 finding)."""
     sys.path.insert(0, ROOT)
     import bench
-    t = bench.pmc_traffic("gemm_kernel<256, 320, 4, 2, 1, false, true>")
-    assert t is not None and 1e8 < t < 1e10            # ~0.8 GB of HBM traffic per conv-GEMM launch
-    assert bench.pmc_traffic("no_such_kernel") is None
+    import vdx  # noqa: F401
+    from vdx._lib import source_sha
+    k = "gemm_kernel<256, 320, 4, 2, 1, false, true>"
+    prof = {k: {"launches": 70, "hbm_read_bytes_per_launch": 6.0e8, "hbm_write_bytes_per_launch": 1.7e8, "mfma_busy": 0.5},
+            "_meta": {"source_sha": source_sha(), "forwards": 2, "hbm_bytes_all_kernels": 8.0e11, "kernels": [k]}}
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps(prof))
+    monkeypatch.setattr(bench, "PMC_JSON", str(f))
+    t, per_step, note = bench.pmc_traffic(k)
+    assert t == 770000000 and per_step == 400000000000 and note is None
+    assert bench.pmc_traffic("no_such_kernel")[0] is None
+    prof["_meta"]["source_sha"] = "0000000000000000"
+    f.write_text(json.dumps(prof))
+    t, per_step, note = bench.pmc_traffic(k)
+    assert t is None and per_step is None and "0000000000000000" in note
+    monkeypatch.setattr(bench, "PMC_JSON", str(tmp_path / "missing.json"))
+    assert bench.pmc_traffic(k)[0] is None
+
+
+def test_bench_selects_the_baseline_configuration_of_the_world_size():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.select_config(1) == ("cfg2", 24, "mono")
+    assert bench.select_config(2) == ("cfg3", 24, "fsdp")
+    assert bench.select_config(4) == ("cfg4", 48, "hybrid")
+    assert bench.select_config(8) == ("cfg5", 96, "hybrid_ctx")
+    assert bench.select_config(3) == ("generic-3", 36, "hybrid_ctx")
+    assert bench.select_config(1, "cfg5") == ("cfg5", 96, "hybrid_ctx")
+    # the planner on those: SURVEY a1 known answers
+    from vdx.planner import plan
+    assert plan(24, 2, 0, 4, no_chunking=True).ranges == ((0, 24), (0, 24))
+    assert plan(48, 4, 0, 4).ranges == ((0, 16), (12, 28), (24, 40), (36, 48))
+    assert plan(96, 8, 0, 4).ranges[-2:] == ((72, 88), (84, 96)) and len(plan(96, 8, 0, 4).ranges) == 8

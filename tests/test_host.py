@@ -119,7 +119,10 @@ def test_unet_weight_ingest_covers_every_diffusers_key():
     m = UNet3DConditionModel(UNet3DConfig.zeroscope())
     m.load_diffusers_state_dict(sd, device="meta")
     # + conv_out rows padded 4 -> 64, conv_in K padded 36 -> 64
-    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28
+    # + the K7 stage images (a second, re-laid-out copy of the temporal q|k|v / to_out weights at widths 320 and 512;
+    #   to_out padded to the q|k|v stage size): 5 level-0 temporal transformers and transformer_in, 2 attentions each
+    k7 = 10 * (3 * 320 * 320 + 2 * 10 * 6144) + 2 * (3 * 512 * 512 + 2 * 16 * 12288)
+    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7
     assert m.config.in_channels == 4
     sd["bogus.weight"] = torch.empty(1, device="meta")
     with pytest.raises(_lib.VdxError):

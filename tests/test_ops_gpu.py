@@ -407,6 +407,63 @@ def test_temporal_attention(gpu, B, Fr, HW, heads):
     close(out, ref, tol=4e-3)
 
 
+def _temporal_block_ref(t, gamma, beta, wq, wk, wv, wo, bo, B, Fr, HW, heads):
+    """fp32 statement of `s = s + attn(LN(s))` of TransformerTemporalModel on rows [(b*F+f)*HW+p][inner]."""
+    inner = t.shape[1]
+    ln = F.layer_norm(t, (inner,), gamma, beta, 1e-5)
+    q, k, v = ln @ wq.t(), ln @ wk.t(), ln @ wv.t()
+    seq = lambda x: x.reshape(B, Fr, HW, inner).permute(0, 2, 1, 3).reshape(B * HW, Fr, inner)   # noqa: E731
+    o = _attn_ref(seq(q), seq(k), seq(v), heads)
+    o = o.reshape(B, HW, Fr, inner).permute(0, 2, 1, 3).reshape(B * Fr * HW, inner)
+    return t + o @ wo.t() + bo
+
+
+@pytest.mark.parametrize("inner,B,Fr,HW", [(320, 2, 24, 20), (320, 1, 16, 7), (320, 2, 12, 9), (320, 1, 8, 5),
+                                           (320, 1, 24, 1), (320, 2, 6, 33), (320, 1, 48, 3), (320, 1, 1, 100),
+                                           (512, 2, 24, 10), (512, 1, 16, 6), (512, 2, 12, 13), (512, 1, 3, 50)])
+def test_temporal_attn_block_fused(gpu, inner, B, Fr, HW):
+    """K7 (csrc/tattn_fused.hip): LayerNorm -> q|k|v -> attention over the frames of each pixel -> to_out + bias +
+    residual in one kernel, against the fp32 reference and against the un-fused kernels it replaces.  Shapes cover
+    F in {24, 16, 12} (the BASELINE chunks) and other divisors of 48, pixel counts that do not fill the last row
+    group / the last block, and both widths the kernel is built for."""
+    ops, _ = _ops()
+    from vdx import packing
+    heads = inner // 64
+    g = torch.Generator().manual_seed(inner + Fr + HW)
+    M = B * Fr * HW
+    t = h(torch.randn(M, inner, generator=g) * 1.5 + 0.3)
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    wq, wk, wv, wo = (h(torch.randn(inner, inner, generator=g) * s_) for s_ in (0.09, 0.09, 0.06, 0.05))
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    ref = _temporal_block_ref(t, gamma, beta, wq, wk, wv, wo, bo, B, Fr, HW, heads)
+    d = lambda x: x.half().to(gpu)   # noqa: E731
+    assert ops.temporal_attn_block_supported(inner, Fr)
+    out = ops.temporal_attn_block(d(t), d(gamma), d(beta), d(packing.pack_k7_qkv(wq, wk, wv)), d(packing.pack_k7_out(wo)),
+                                  d(bo), B=B, F=Fr, HW=HW, scale=0.125)
+    close(out, ref, tol=4e-3)
+    # the un-fused chain (LayerNorm, q|k|v GEMM, attention core, output GEMM with residual)
+    ln = ops.layernorm(d(t), d(gamma), d(beta), M=M)
+    qkv = ops.gemm(ln, d(torch.cat([wq, wk, wv], 0)), M=M)
+    o = ops.temporal_attn(qkv, B=B, F=Fr, HW=HW, heads=heads, scale=0.125)
+    unf = ops.gemm(o, d(wo), M=M, bias=d(bo), residual=d(t))
+    close(out, unf.float().cpu(), tol=3e-3)
+    # a second launch gives the same bits (no dependence on block scheduling)
+    out2 = ops.temporal_attn_block(d(t), d(gamma), d(beta), d(packing.pack_k7_qkv(wq, wk, wv)), d(packing.pack_k7_out(wo)),
+                                   d(bo), B=B, F=Fr, HW=HW, scale=0.125)
+    assert torch.equal(out, out2)
+
+
+def test_temporal_attn_block_rejects_unsupported(gpu):
+    ops, _ = _ops()
+    from vdx._lib import VdxError
+    assert not ops.temporal_attn_block_supported(320, 5) and not ops.temporal_attn_block_supported(640, 24)
+    t = torch.zeros(5 * 4, 320, dtype=torch.float16, device=gpu)
+    v = torch.zeros(320, dtype=torch.float16, device=gpu)
+    w = torch.zeros(16, dtype=torch.float16, device=gpu)
+    with pytest.raises(VdxError):
+        ops.temporal_attn_block(t, v, v, w, w, v, B=1, F=5, HW=4, scale=0.125)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_conv_in_and_output_permute(gpu):
     ops, packing = _ops()

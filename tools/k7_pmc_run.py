@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Dev tool: a few launches of the fused temporal-attention kernel at level-0 size, for rocprofv3 --pmc passes."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vdx  # noqa: E402,F401
+from vdx import ops, packing  # noqa: E402
+
+dev = torch.device("cuda:0")
+for inner in (320, 512):
+    B, F, HW = 2, 24, 72 * 128
+    M = B * F * HW
+    t = torch.randn(M, inner, device=dev).half()
+    v = lambda s=0.1: (torch.randn(inner, device=dev) * s).half()   # noqa: E731
+    w = [(torch.randn(inner, inner, device=dev) * 0.06).half() for _ in range(4)]
+    pq, po = packing.pack_k7_qkv(*w[:3]).contiguous(), packing.pack_k7_out(w[3]).contiguous()
+    out = torch.empty_like(t)
+    g, b_, bo = v() + 1, v(), v()
+    for _ in range(4):
+        ops.temporal_attn_block(t, g, b_, pq, po, bo, B=B, F=F, HW=HW, scale=0.125, out=out)
+    torch.cuda.synchronize()
