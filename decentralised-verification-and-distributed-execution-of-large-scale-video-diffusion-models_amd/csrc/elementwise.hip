@@ -88,6 +88,28 @@ extern "C" int vdx_silu_f16(const void* x, void* y, size_t n, vdx_stream_t strea
     return vdx_launch_status("vdx_silu_f16");
 }
 
+// ---- sinusoidal timestep embedding (diffusers `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)`,
+// SURVEY.md Appendix A.2): emb[b] = [cos(t * f_0..f_{h-1}) | sin(t * f_0..f_{h-1})], f_j = exp(-ln(10000) * j / h),
+// h = dim / 2, computed in fp32 and stored fp16 like the reference's `t_emb.to(dtype)`.  The timestep is read from
+// DEVICE memory, so a forward needs no host value of it (no sync on device-tensor timesteps, nothing to copy per step).
+__global__ void timestep_embedding_kernel(const float* t, f16* out, int B, int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, c = i - b * dim;
+    const int j = c < half ? c : c - half;
+    const float f = expf(-9.210340371976184f * (float)j / (float)half);
+    const float a = t[0] * f;
+    out[i] = (f16)(c < half ? cosf(a) : sinf(a));
+}
+extern "C" int vdx_timestep_embedding_f16(const float* t_device, void* out, int B, int dim, vdx_stream_t stream) {
+    VDX_CHECK(t_device && out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad arguments");
+    const int n = B * dim;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t_device,
+                       (f16*)out, B, dim);
+    return vdx_launch_status("vdx_timestep_embedding_f16");
+}
+
 // ---- exact GELU (CLIP text tower MLP) ---------------------------------------------------------
 __global__ void gelu_kernel(const f16* x, f16* y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

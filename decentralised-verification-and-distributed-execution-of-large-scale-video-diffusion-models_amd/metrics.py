@@ -2,9 +2,10 @@
 reduction and the CSV contract that `Distribution/plot_helpers/plot.py:7-13` reads.
 
 `temp_instab` (mean absolute difference of the two frames either side of every chunk boundary) is restated
-exactly (:227-247, host numpy on the decoded uint8 frames, as the reference computes it).  `flow_err` (:236-245)
-needs cv2's Farneback optical flow and remap, which this stack does not provide: the column is written empty
-(the reference writes an empty cell too whenever the metric is None, e.g. for a single chunk) — documented gap.
+exactly (:227-247, host numpy on the decoded uint8 frames, as the reference computes it).  `flow_err` (:236-245) is
+the same loop with OpenCV's Farneback flow + remap; `cv2` is taken from the environment when it is installed and
+from `vdx.compat.cv2_shim` (an own implementation of the published algorithm) otherwise — with the shim the number
+is not pinned against OpenCV's ("parity unpinned", see the shim's docstring).  `write_video` is :250-253.
 """
 from __future__ import annotations
 
@@ -32,6 +33,47 @@ def boundary_l1(frames: Sequence[np.ndarray], ranges: Sequence[Tuple[int, int]])
     diffs = [np.mean(np.abs(frames[e].astype(np.float32) - frames[e - 1].astype(np.float32)))
              for e in ends if 0 < e < len(frames)]
     return float(np.mean(diffs)) if diffs else None
+
+
+def _cv2():
+    try:
+        import cv2
+        return cv2
+    except ImportError:
+        from .compat import cv2_shim
+        return cv2_shim
+
+
+def flow_warp_error(frames: Sequence[np.ndarray], ranges: Sequence[Tuple[int, int]]) -> Optional[float]:
+    """:229-246 — at every chunk boundary: Farneback flow prev -> next (pyr 0.5, 3 levels, window 15, 3 iterations,
+    poly 5 / 1.2), warp prev by it (remap, bilinear) and take the mean absolute difference to next."""
+    cv2 = _cv2()
+    if len(frames) <= 1:
+        return None
+    ends = [e for (_s, e) in sorted(ranges, key=lambda r: r[0])[:-1]]
+    diffs = []
+    for e in ends:
+        if not 0 < e < len(frames):
+            continue
+        f_prev, f_next = frames[e - 1], frames[e]
+        prev_gray, next_gray = cv2.cvtColor(f_prev, cv2.COLOR_BGR2GRAY), cv2.cvtColor(f_next, cv2.COLOR_BGR2GRAY)
+        flow = cv2.calcOpticalFlowFarneback(prev_gray, next_gray, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+        h, w = prev_gray.shape
+        flow_x = (np.arange(w)[None, :] + flow[:, :, 0]).astype(np.float32)
+        flow_y = (np.arange(h)[:, None] + flow[:, :, 1]).astype(np.float32)
+        warp_prev = cv2.remap(f_prev, flow_x, flow_y, cv2.INTER_LINEAR)
+        diffs.append(np.mean(np.abs(warp_prev.astype(np.float32) - f_next.astype(np.float32))))
+    return float(np.mean(diffs)) if diffs else None
+
+
+def write_video(frames: Sequence[np.ndarray], path: str, fps: float) -> None:
+    """:250-253 — `cv2.VideoWriter(path, fourcc("mp4v"), fps, (W, H))`, frames RGB -> BGR, release."""
+    cv2 = _cv2()
+    h, w = frames[0].shape[:2]
+    vw = cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"mp4v"), fps, (w, h))
+    for f in frames:
+        vw.write(cv2.cvtColor(f, cv2.COLOR_RGB2BGR))
+    vw.release()
 
 
 def peak_vram_mb(device) -> Tuple[int, float]:

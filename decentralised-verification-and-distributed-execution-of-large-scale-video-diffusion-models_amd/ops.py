@@ -196,6 +196,18 @@ def silu(x, out=None):
     return out
 
 
+def timestep_embedding(t_dev, B, dim, out=None):
+    """Sinusoidal embedding of ONE fp32 timestep held in device memory -> fp16 [B][dim] (include/vdx.h)."""
+    lib = _lib.load()
+    if t_dev.dtype != torch.float32 or t_dev.numel() != 1:
+        raise VdxError("timestep_embedding: t must be one fp32 value on the GPU")
+    if out is None:
+        out = torch.empty((B, dim), dtype=torch.float16, device=t_dev.device)
+    _lib.check(lib.vdx_timestep_embedding_f16(_p(t_dev, "t", torch.float32), _p(out, "out"), B, dim, _stream()),
+               "vdx_timestep_embedding_f16")
+    return out
+
+
 def gelu(x, out=None):
     lib = _lib.load()
     if not x.is_contiguous():

@@ -39,6 +39,7 @@ class DDIMScheduler:
         self.num_inference_steps = None
         self.timesteps = None
         self._host_timesteps = None
+        self._cursor = 0
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         n_train = self.config.num_train_timesteps
@@ -50,6 +51,7 @@ class DDIMScheduler:
         ts += self.config.steps_offset
         self._host_timesteps = [int(t) for t in ts]
         self.timesteps = torch.from_numpy(ts).to(device)
+        self._cursor = 0
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -61,14 +63,27 @@ class DDIMScheduler:
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         return (float((1 - a_t) ** 0.5), float(a_t ** 0.5), float(a_prev ** 0.5), float((1 - a_prev) ** 0.5))
 
+    def _host_timestep(self, timestep) -> int:
+        """The step's timestep as a host integer WITHOUT reading device memory.  The reference hands `step` the 0-d
+        device tensors it iterates over (`for t in scheduler.timesteps`, :132,142); `int(t)` on those is a device
+        sync per step.  Like diffusers' own step-index bookkeeping, a device-tensor timestep is taken to be the next
+        one of the schedule (wrapping after the last: the reference runs `_denoise` once per chunk, :186-189);
+        Python numbers and host tensors are used as given."""
+        if torch.is_tensor(timestep) and timestep.is_cuda:
+            t = self._host_timesteps[self._cursor % len(self._host_timesteps)]
+            self._cursor += 1
+            return t
+        return int(timestep)
+
     def step(self, model_output, timestep, sample, eta: float = 0.0, **_unused):
         if eta != 0.0:
             raise NotImplementedError("eta != 0 is not used by the reference path")
         if self.num_inference_steps is None:
             raise ValueError("call set_timesteps first")
-        prev = ops.ddim_step(model_output.contiguous(), sample.contiguous(), self.coefficients(int(timestep)))
+        prev = ops.ddim_step(model_output.contiguous(), sample.contiguous(),
+                             self.coefficients(self._host_timestep(timestep)))
         return SimpleNamespace(prev_sample=prev)
 
     def step_cfg(self, noise2, timestep, sample, guidance_scale: float):
         """Fused `u + gs*(c-u)` + step (fsdp_chunked_coherent.py:141-142) in one kernel."""
-        return ops.cfg_ddim_step(noise2, sample, guidance_scale, self.coefficients(int(timestep)))
+        return ops.cfg_ddim_step(noise2, sample, guidance_scale, self.coefficients(self._host_timestep(timestep)))

@@ -75,6 +75,8 @@ class UNet3DConditionModel(nn.Module):
         self.dtype = torch.float16
         self.ff_block_bytes = None     # memory-lean feed-forward (see _ff); shard_() turns it on
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
+        self._text_ref = None                  # (encoder_hidden_states object, its version, (B, device), padded copy)
+        self._text_kv: Dict[str, tuple] = {}   # cross-attention K / V^T of that text, per transformer
 
     # ------------------------------------------------------------------------------------------
     # weights
@@ -213,6 +215,7 @@ class UNet3DConditionModel(nn.Module):
             raise VdxError(f"unexpected keys in state dict: {sorted(missing)[:5]} ... ({len(missing)})")
         self.W = W
         self._device = dev
+        self._text_ref, self._text_kv = None, {}
         return self
 
     def _apply(self, fn, recurse=True):
@@ -392,8 +395,13 @@ class UNet3DConditionModel(nn.Module):
         q = ops.gemm(ln, W[b + ".attn2.to_q.weight"], M=M)
         del ln
         nb = ehs_pad.shape[0] // TEXT_PAD
-        k = ops.gemm(ehs_pad, W[b + ".attn2.to_k.weight"], M=ehs_pad.shape[0])
-        vt = ops.gemm(W[b + ".attn2.to_v.weight"], ehs_pad, M=C)                  # [C][nb*TEXT_PAD]
+        kv = self._text_kv.get(p)
+        if kv is None:
+            k = ops.gemm(ehs_pad, W[b + ".attn2.to_k.weight"], M=ehs_pad.shape[0])
+            vt = ops.gemm(W[b + ".attn2.to_v.weight"], ehs_pad, M=C)              # [C][nb*TEXT_PAD]
+            self._text_kv[p] = (k, vt)
+        else:
+            k, vt = kv
         o = ops.flash_attn(q, k, vt, n_seq=n_img, sq=S, skv=self._text_len, skv_pad=TEXT_PAD, heads=heads,
                            seq_per_kv=n_img // nb, scale=scale)
         del q
@@ -429,12 +437,16 @@ class UNet3DConditionModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _time_embedding(self, timestep, B, device):
-        c0 = self.cfg.block_out_channels[0]
-        t = float(timestep)
-        half = c0 // 2
-        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
-        a = torch.full((B, 1), t, dtype=torch.float32) * freqs[None]
-        return torch.cat([torch.cos(a), torch.sin(a)], dim=-1).to(torch.float16).to(device)
+        """`Timesteps` on the device.  The timestep never has to exist on the host: a device tensor (the
+        reference iterates `scheduler.timesteps`, 0-d int64 on the GPU, :132) is converted in place — no `float(t)`
+        sync — and a Python number becomes a one-element fill."""
+        if torch.is_tensor(timestep):
+            t = timestep.to(device=device, dtype=torch.float32).reshape(-1)[:1]
+            if t.data_ptr() % 16:
+                t = t.clone()
+        else:
+            t = torch.full((1,), float(timestep), dtype=torch.float32, device=device)
+        return ops.timestep_embedding(t.contiguous(), B, self.cfg.block_out_channels[0])
 
     @torch.no_grad()
     def forward(self, sample, timestep, encoder_hidden_states, **_unused):
@@ -460,8 +472,18 @@ class UNet3DConditionModel(nn.Module):
         if ehs.shape[0] != B or ehs.shape[2] != c.cross_attention_dim or ehs.shape[1] > TEXT_PAD:
             raise VdxError(f"encoder_hidden_states shape {tuple(ehs.shape)} does not fit (B={B}, dim={c.cross_attention_dim})")
         self._text_len = ehs.shape[1]
-        ehs_pad = torch.zeros((B * TEXT_PAD, c.cross_attention_dim), dtype=torch.float16, device=dev)
-        ehs_pad.view(B, TEXT_PAD, -1)[:, :ehs.shape[1]] = ehs
+        # The text keys / values of the 16 cross-attentions depend on the prompt only: they are projected on the first
+        # step and kept while the caller keeps passing the SAME tensor object, unmodified (the denoising loop hands the
+        # same `emb` to all 50 steps, fsdp_chunked_coherent.py:138-140).  Identity + version, not the address: a new
+        # tensor may reuse a freed address with other contents.
+        ref = self._text_ref
+        if not (ref is not None and ref[0] is encoder_hidden_states and ref[1] == encoder_hidden_states._version
+                and ref[2] == (B, dev)):
+            ehs_pad = torch.zeros((B * TEXT_PAD, c.cross_attention_dim), dtype=torch.float16, device=dev)
+            ehs_pad.view(B, TEXT_PAD, -1)[:, :ehs.shape[1]] = ehs
+            self._text_ref = (encoder_hidden_states, encoder_hidden_states._version, (B, dev), ehs_pad)
+            self._text_kv = {}
+        ehs_pad = self._text_ref[3]
         n_img = B * F
 
         # time embedding -> all time_emb_proj outputs [B][sum Cout]

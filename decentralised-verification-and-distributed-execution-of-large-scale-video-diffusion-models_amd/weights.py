@@ -128,3 +128,77 @@ def synthetic_state_dict(cfg: UNet3DConfig, seed: int = 1234, device="cpu", dtyp
             t = 0.02 * torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
         out[name] = t.to(dtype)
     return out
+
+
+def synthetic_vae_state_dict(cfg=None, seed: int = 7, device="cpu", dtype=torch.float16):
+    """diffusers-shaped AutoencoderKL DECODER table (+ post_quant_conv) with seeded values: what `vdx.vae.AutoencoderKL.
+    load_diffusers_state_dict` ingests when no checkpoint exists (bench / compat runs)."""
+    from .vae import VaeConfig
+    cfg = cfg or VaeConfig.sd()
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rev = tuple(reversed(cfg.block_out_channels))
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = (torch.randn(co, ci, k, k, generator=g, device=dev) / (ci * k * k) ** 0.5).to(dtype)
+        sd[name + ".bias"] = (0.02 * torch.randn(co, generator=g, device=dev)).to(dtype)
+
+    def norm(name, c):
+        sd[name + ".weight"] = (1 + 0.05 * torch.randn(c, generator=g, device=dev)).to(dtype)
+        sd[name + ".bias"] = (0.02 * torch.randn(c, generator=g, device=dev)).to(dtype)
+
+    def resnet(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", co, ci, 3); norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".conv_shortcut", co, ci, 1)
+
+    conv("post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+    conv("decoder.conv_in", rev[0], cfg.latent_channels, 3)
+    resnet("decoder.mid_block.resnets.0", rev[0], rev[0])
+    a = "decoder.mid_block.attentions.0"
+    norm(a + ".group_norm", rev[0])
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        sd[f"{a}.{n}.weight"] = (torch.randn(rev[0], rev[0], generator=g, device=dev) / rev[0] ** 0.5).to(dtype)
+        sd[f"{a}.{n}.bias"] = (0.02 * torch.randn(rev[0], generator=g, device=dev)).to(dtype)
+    resnet("decoder.mid_block.resnets.1", rev[0], rev[0])
+    prev = rev[0]
+    for i, ch in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else ch, ch)
+        if i != len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", ch, ch, 3)
+        prev = ch
+    norm("decoder.conv_norm_out", rev[-1])
+    conv("decoder.conv_out", cfg.out_channels, rev[-1], 3)
+    return sd
+
+
+def synthetic_clip_state_dict(cfg=None, seed: int = 11, device="cpu", dtype=torch.float16):
+    """`transformers.CLIPTextModel`-shaped table (keys without the `text_model.` prefix) with seeded values."""
+    from .clip_text import CLIPTextConfig
+    cfg = cfg or CLIPTextConfig.sd2()
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    d, f = cfg.hidden_size, cfg.intermediate_size
+    sd = {}
+
+    def lin(name, co, ci):
+        sd[name + ".weight"] = (torch.randn(co, ci, generator=g, device=dev) / ci ** 0.5).to(dtype)
+        sd[name + ".bias"] = (0.02 * torch.randn(co, generator=g, device=dev)).to(dtype)
+
+    def norm(name):
+        sd[name + ".weight"] = (1 + 0.05 * torch.randn(d, generator=g, device=dev)).to(dtype)
+        sd[name + ".bias"] = (0.02 * torch.randn(d, generator=g, device=dev)).to(dtype)
+
+    sd["embeddings.token_embedding.weight"] = (0.5 * torch.randn(cfg.vocab_size, d, generator=g, device=dev)).to(dtype)
+    sd["embeddings.position_embedding.weight"] = (0.1 * torch.randn(cfg.max_position_embeddings, d, generator=g, device=dev)).to(dtype)
+    for i in range(cfg.num_hidden_layers):
+        p = f"encoder.layers.{i}"
+        norm(p + ".layer_norm1"); norm(p + ".layer_norm2")
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(f"{p}.self_attn.{n}", d, d)
+        lin(p + ".mlp.fc1", f, d)
+        lin(p + ".mlp.fc2", d, f)
+    norm("final_layer_norm")
+    return sd

@@ -80,6 +80,11 @@ int vdx_rows_to_ncfhw_f16(const void* rows, int ld, void* out, int B, int C, int
 /* y = x * sigmoid(x), n elements (TimestepEmbedding act / ResnetBlock2D.nonlinearity(temb)) */
 int vdx_silu_f16(const void* x, void* y, size_t n, vdx_stream_t stream);
 
+/* Sinusoidal timestep embedding of UNet3DConditionModel (`Timesteps(320, flip_sin_to_cos=True, shift 0)`):
+ * out[b][0:dim/2] = cos(t*f_j), out[b][dim/2:] = sin(t*f_j), f_j = exp(-ln(1e4) j / (dim/2)); fp32 math, fp16 store.
+ * `t_device` points at ONE fp32 timestep in device memory (all B batch items share it, fsdp_chunked_coherent.py:140). */
+int vdx_timestep_embedding_f16(const float* t_device, void* out, int B, int dim, vdx_stream_t stream);
+
 /* y = gelu(x) (exact, erf), n elements: CLIPMLP's activation between fc1 and fc2 (hidden_act "gelu") */
 int vdx_gelu_f16(const void* x, void* y, size_t n, vdx_stream_t stream);
 
