@@ -20,7 +20,7 @@ struct GnP {
     int c1, c2, ldx, ldx2;
     int C, G, cpg, nvec, krows;      // nvec = C/8, krows = rows processed in parallel per block
     int n_samples, rps, nslabs, slab_rows;   // rps = rows per sample
-    float* partial;                  // [n_samples][nslabs][G][2]  (sum, sumsq)
+    float* partial;                  // [n_samples][nslabs][G][3]  (count, mean, M2)
     float* ab;                       // [n_samples][C][2]          (scale, shift)
 };
 
@@ -30,64 +30,117 @@ __device__ __forceinline__ f16x8 gn_load(const GnP& p, size_t row, int cv) {
     return *(const f16x8*)src;
 }
 
+// Statistics are (count, mean, M2 = sum of squared deviations) triples merged pairwise (Chan et al.):
+//   n = na + nb,  d = mb - ma,  mean = ma + d * nb / n,  M2 = M2a + M2b + d^2 * na * nb / n.
+// A thread sums its rows SHIFTED by the first value it sees per channel (sum (x - k), sum (x - k)^2), so nothing of
+// the size of the mean is ever squared: E[x^2] - mean^2 from plain fp32 sums loses the variance of a group whose mean
+// is a few hundred standard deviations out (large-mean channels of trained checkpoints); this form does not.
+struct Moments {
+    float n, mean, m2;
+};
+__device__ __forceinline__ Moments merge(const Moments a, const Moments b) {
+    if (b.n == 0.f) return a;
+    if (a.n == 0.f) return b;
+    const float n = a.n + b.n, d = b.mean - a.mean;
+    return Moments{n, a.mean + d * (b.n / n), a.m2 + b.m2 + d * d * (a.n * b.n / n)};
+}
+
 __global__ void gn_partial_kernel(const GnP p) {
-    // [2][krows][C] per-thread channel sums; reduced to groups in a FIXED order (no float atomics:
-    // the statistics, and therefore every output of the network, are bitwise reproducible)
+    // [2][krows][C] per-thread channel (mean, M2) + [krows] row counts; reduced to groups in a FIXED order (no float
+    // atomics: the statistics, and therefore every output of the network, are bitwise reproducible)
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int sample = blockIdx.y, slab = blockIdx.x;
     const int cv = tid % p.nvec, rsub = tid / p.nvec;
-    float s[8], ss[8];
+    float k[8], s[8], ss[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+    for (int j = 0; j < 8; ++j) k[j] = s[j] = ss[j] = 0.f;
     const int r_end = min(p.rps, (slab + 1) * p.slab_rows);
-    for (int r = slab * p.slab_rows + rsub; r < r_end; r += p.krows) {
+    int cnt = 0;
+    for (int r = slab * p.slab_rows + rsub; r < r_end; r += p.krows, ++cnt) {
         const f16x8 v = gn_load(p, (size_t)sample * p.rps + r, cv);
+        if (cnt == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) k[j] = (float)v[j];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float f = (float)v[j];
+            const float f = (float)v[j] - k[j];
             s[j] += f;
             ss[j] += f * f;
         }
     }
     const int plane = p.krows * p.C;
+    const float inv = cnt ? 1.0f / (float)cnt : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        lds[rsub * p.C + cv * 8 + j] = s[j];
-        lds[plane + rsub * p.C + cv * 8 + j] = ss[j];
+        lds[rsub * p.C + cv * 8 + j] = k[j] + s[j] * inv;                     // mean of this thread's rows
+        lds[plane + rsub * p.C + cv * 8 + j] = ss[j] - s[j] * s[j] * inv;     // their M2 (shifted: no cancellation)
+    }
+    if (cv == 0) lds[2 * plane + rsub] = (float)cnt;
+    __syncthreads();
+    // (group, row subset) pairs first: the cpg channel triples of one row subset all have the same count, so their
+    // merge needs no division per step: mean = average of the means, M2 = sum M2 + n * sum (mean_c - mean)^2
+    float* tmp = lds + 2 * plane + p.krows;                 // [G * krows][2]
+    for (int i = tid; i < p.G * p.krows; i += blockDim.x) {
+        const int g = i / p.krows, r = i - g * p.krows;
+        const float* mp = lds + r * p.C + g * p.cpg;
+        const float* qp = lds + plane + r * p.C + g * p.cpg;
+        float ms = 0.f, qs = 0.f;
+        for (int c = 0; c < p.cpg; ++c) {
+            ms += mp[c];
+            qs += qp[c];
+        }
+        const float mean = ms / (float)p.cpg;
+        float dev = 0.f;
+        for (int c = 0; c < p.cpg; ++c) {
+            const float d = mp[c] - mean;
+            dev += d * d;
+        }
+        tmp[2 * i] = mean;
+        tmp[2 * i + 1] = qs + lds[2 * plane + r] * dev;
     }
     __syncthreads();
-    float* dst = p.partial + ((size_t)sample * p.nslabs + slab) * 2 * p.G;
-    for (int i = tid; i < 2 * p.G; i += blockDim.x) {
-        const int g = i >> 1;
-        const float* src = lds + (i & 1) * plane + g * p.cpg;
-        float acc = 0.f;
+    float* dst = p.partial + ((size_t)sample * p.nslabs + slab) * 3 * p.G;
+    for (int g = tid; g < p.G; g += blockDim.x) {
+        Moments m{0.f, 0.f, 0.f};
         for (int r = 0; r < p.krows; ++r)
-            for (int c = 0; c < p.cpg; ++c) acc += src[r * p.C + c];
-        dst[i] = acc;
+            m = merge(m, Moments{lds[2 * plane + r] * (float)p.cpg, tmp[2 * (g * p.krows + r)], tmp[2 * (g * p.krows + r) + 1]});
+        dst[3 * g] = m.n;
+        dst[3 * g + 1] = m.mean;
+        dst[3 * g + 2] = m.m2;
     }
 }
 
-// one wave per (sample, group): combine slab partials in double, emit per-channel scale/shift
+// one wave per (sample, group): merge the slab triples in double, emit per-channel scale/shift
 __global__ void gn_finalize_kernel(const GnP p, const f16* gamma, const f16* beta, float eps) {
     const int lane = threadIdx.x & 63;
     const int sg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (sg >= p.n_samples * p.G) return;
     const int sample = sg / p.G, g = sg % p.G;
-    double s = 0.0, ss = 0.0;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    auto merge_d = [&](double nb, double mb, double m2b) {
+        if (nb == 0.0) return;
+        const double nn = n + nb, d = mb - mean;
+        m2 += m2b + d * d * (n * nb / nn);
+        mean += d * (nb / nn);
+        n = nn;
+    };
     for (int i = lane; i < p.nslabs; i += 64) {
-        const float* src = p.partial + ((size_t)sample * p.nslabs + i) * 2 * p.G + 2 * g;
-        s += (double)src[0];
-        ss += (double)src[1];
+        const float* src = p.partial + ((size_t)sample * p.nslabs + i) * 3 * p.G + 3 * g;
+        merge_d((double)src[0], (double)src[1], (double)src[2]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        ss += __shfl_xor(ss, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {                      // fixed butterfly order: reproducible
+        const double nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
+        // both partners must end with the same value: merge symmetrically (lower lane's triple first)
+        const bool low = (lane & o) == 0;
+        const double na = low ? n : nb, ma = low ? mean : mb, m2a = low ? m2 : m2b;
+        const double nc = low ? nb : n, mc = low ? mb : mean, m2c = low ? m2b : m2;
+        n = na; mean = ma; m2 = m2a;
+        merge_d(nc, mc, m2c);
     }
-    const double n = (double)p.rps * p.cpg;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
+    double var = n > 0.0 ? m2 / n : 0.0;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int j = lane; j < p.cpg; j += 64) {
@@ -135,7 +188,7 @@ static int gn_threads(int nvec, int* krows) {
 extern "C" size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G) {
     const int rows = gn_slab_rows(n_samples, rows_per_sample);
     const size_t nslabs = (rows_per_sample + rows - 1) / rows;
-    return ((size_t)n_samples * nslabs * G * 2 + (size_t)n_samples * C * 2) * sizeof(float);
+    return ((size_t)n_samples * nslabs * G * 3 + (size_t)n_samples * C * 2) * sizeof(float);
 }
 
 extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
@@ -157,11 +210,11 @@ extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2,
     p.slab_rows = gn_slab_rows(n_samples, rows_per_sample);
     p.nslabs = (rows_per_sample + p.slab_rows - 1) / p.slab_rows;
     p.partial = (float*)workspace;
-    p.ab = p.partial + (size_t)n_samples * p.nslabs * G * 2;
+    p.ab = p.partial + (size_t)n_samples * p.nslabs * G * 3;
     const int nt = gn_threads(p.nvec, &p.krows);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.nslabs, n_samples);
-    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), 2 * (size_t)p.krows * C * sizeof(float), st, p);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), (2 * (size_t)p.krows * C + p.krows + 2 * (size_t)G * p.krows) * sizeof(float), st, p);
     const int nsg = n_samples * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, st, p, (const f16*)gamma, (const f16*)beta, eps);
     if (silu)

@@ -18,9 +18,13 @@ build container, is not vendored under /root/reference, and the reference
 holds no test, fixture or golden vector for any UNet / scheduler / blended
 latent result.  What *is* pinned:
   * planner / blend / noise semantics — hand-executed known-answer tables from
-    the reference source (tests/test_oracle_planner.py, test_oracle_blend.py)
-    plus the one committed notebook known answer
-    (`Distribution/legacy/Latent Chunking/latent_chunking.ipynb:173-176`);
+    the reference source (tests/test_oracle_host.py, tests/test_host.py,
+    tests/test_halo_host.py) plus the two committed notebook known answers:
+    the chunk split (`Distribution/legacy/Latent Chunking/latent_chunking.ipynb:173-176`)
+    and the shared-vs-independent overlap-noise statistics 0.0000 / 1.9990
+    (`.../shared_overlap_noise/chunking_benchmark copy.ipynb:589-619`,
+    restated in tests/test_oracle_host.py);
   * the UNet structure — total parameter count 1 411 233 860, per-block totals
-    and the diffusers state-dict key/shape table (tests/test_oracle_unet.py).
+    and the diffusers state-dict key/shape table (tests/test_oracle_host.py,
+    tests/test_host.py).
 """

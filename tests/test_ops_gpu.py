@@ -269,6 +269,22 @@ def test_groupnorm(gpu, ns, rps, c1, c2, G, silu):
     close(out, ref, tol=4e-3)
 
 
+@pytest.mark.parametrize("ns,rps,C,mean,std", [(3, 300, 320, 60.0, 1.0), (2, 20000, 64, 1500.0, 4.0), (1, 9216 * 4, 320, -700.0, 2.0)])
+def test_groupnorm_large_mean(gpu, ns, rps, C, mean, std):
+    """Groups whose mean is tens to hundreds of standard deviations away from 0 (large-mean channels of trained
+    checkpoints): E[x^2] - mean^2 from fp32 sums loses the variance there; the kernel's shifted sums merged with
+    Chan's formula must not.  Reference = fp64 GroupNorm of the same fp16 data."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(int(abs(mean)) + rps)
+    x = h(torch.randn(ns * rps, C, generator=g) * std + mean + 0.1 * std * torch.randn(1, C, generator=g))
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.3 * torch.randn(C, generator=g))
+    x3 = x.double().reshape(ns, rps, C).permute(0, 2, 1)
+    ref = F.group_norm(x3, 32, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1).reshape(ns * rps, C).float()
+    out = ops.groupnorm(x.half().to(gpu), gamma.half().to(gpu), beta.half().to(gpu), groups=32, n_samples=ns,
+                        rows_per_sample=rps, eps=1e-5, silu_act=False)
+    close(out, ref, tol=4e-3)
+
+
 @pytest.mark.parametrize("M,C", [(37, 64), (100, 320), (9, 1280), (5, 512), (4099, 320), (131, 640), (64, 1280)])
 def test_layernorm(gpu, M, C):
     ops, _ = _ops()

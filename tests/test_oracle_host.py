@@ -1,5 +1,6 @@
 """Pins the oracle's orchestration restatement against known answers hand-executed from the
 reference source and the one committed notebook known answer."""
+import numpy as np
 import pytest
 import torch
 
@@ -108,3 +109,30 @@ def test_blend_weights_kat():
     v = out.flatten()
     # chunk0 w = [0,1,1,1,1,1,1,0]; chunk1 w = [1,0] -> frame 6: (1+1)/2, frame 7: 0/1e-6 = 0
     assert v[0] == 0 and v[7] == 0 and abs(float(v[6]) - 1.0) < 1e-3
+
+
+def test_shared_vs_independent_overlap_noise_notebook_statistics():
+    """The one numeric fixture the reference holds for the shared-noise semantics (a2): its noise-initialisation
+    benchmark (`Distribution/legacy/Latent Chunking/shared_overlap_noise/chunking_benchmark copy.ipynb`, cell 7
+    `generate_noise` / `compute_overlap_similarity`, printed statistics :589-619): 16 frames, chunk 8, overlap 2,
+    latents (1,4,F,64,64).  Windows cut from ONE base tensor agree exactly on their overlap (MSE 0.0000, std 0.0000);
+    independently drawn windows differ by the variance of a difference of two N(0,1): mean 1.9990, std 0.0106 over
+    the notebook's 1000 runs (expected 2 and sqrt(8 / 32768) / sqrt(2) = 0.011).  Restated on the product's noise and
+    window functions (`vdx.pipeline.seeded_noise`, the planner's window walk) and on the oracle's."""
+    import vdx  # noqa: F401
+    from vdx.pipeline import seeded_noise
+    from vdx.planner import _windows
+    from oracle.pipeline_ref import base_noise
+    T, cs, ov = 16, 8, 2
+    wins = _windows(T, cs, ov)
+    assert wins == [(0, 8), (6, 14), (12, 16)]                     # the notebook's range(0, T, cs - ov) split
+
+    def overlap_mse(chunks):
+        return float(np.mean([float(torch.nn.functional.mse_loss(a[:, :, -ov:], b[:, :, :ov])) for a, b in zip(chunks[:-1], chunks[1:])]))
+
+    for base in (seeded_noise((1, 4, T, 64, 64), 1.0, "cpu", "cpu", dtype=torch.float32), base_noise(T, 4, 64, 64, 1.0, torch.float32)):
+        shared = [base[:, :, s:e].clone() for s, e in wins]
+        assert overlap_mse(shared) == 0.0
+    g = torch.Generator().manual_seed(123)
+    runs = [overlap_mse([torch.randn(1, 4, e - s, 64, 64, generator=g) for s, e in wins]) for _ in range(200)]
+    assert abs(np.mean(runs) - 1.9990) < 0.01 and 0.008 < np.std(runs) < 0.014
