@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="N=1 only: run the multi-GPU code path (RCCL init, sharded weights, collectives) with world 1")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--ff-block-mb", type=int, default=0, help="diagnostic: feed-forward row-block size of the memory-lean mode")
+    ap.add_argument("--resident", action="store_true",
+                    help="diagnostic: keep the UNet weights resident (no shard store) in a distributed / rehearsal run")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that print to fd 1 (RCCL's version banner)
@@ -148,8 +151,10 @@ def main():
     H, W = 72, 128
     cfg = UNet3DConfig.zeroscope()
     unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
-    if dist_mode:
+    if dist_mode and not args.resident:
         unet.shard_(rank, world)       # 1/N of every unit per GPU, per-unit RCCL all-gather
+    if args.ff_block_mb:
+        unet.ff_block_bytes = args.ff_block_mb << 20
     sched = DDIMScheduler()
     sched.set_timesteps(50, device=dev)
     plan_world, plan_rank = (args.as_world, args.as_rank) if (args.rehearse_dist and args.as_world) else (world, rank)
@@ -244,6 +249,14 @@ def main():
             "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
             "output_finite": finite,
         }
+        if plan_world != world and hasattr(unet.W, "shards"):
+            # one-GPU rehearsal of a rank of a bigger job: here the whole of every unit stays resident (world of one);
+            # at the planned world size only 1/plan_world of the sharded bytes would.  Estimate, not a measurement.
+            sharded = sum(t.numel() * t.element_size() for t in unet.W.shards.values()) / 2 ** 30
+            est = peak_gb - sharded * (1.0 - 1.0 / plan_world)
+            out["peak_hbm_gb_per_gpu_estimated_at_planned_world"] = round(est, 3)
+            if mono:
+                out["peak_hbm_frac_of_monolithic_estimated_at_planned_world"] = round(est / mono, 4)
         if prof:
             torch.cuda.synchronize()
             agg = {}

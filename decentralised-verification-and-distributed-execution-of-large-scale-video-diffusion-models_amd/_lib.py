@@ -40,6 +40,8 @@ SIGNATURES = {
     "vdx_silu_f16": (_i, [_vp, _vp, _sz, _vp]),
     "vdx_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
     "vdx_groupnorm_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "vdx_groupnorm_workspace_part": (_sz, [_i, _i, _i, _i, _i]),
+    "vdx_groupnorm_part_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "vdx_layernorm_f16": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "vdx_flash_attn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "vdx_timestep_embedding_f16": (_i, [_vp, _vp, _i, _i, _vp]),

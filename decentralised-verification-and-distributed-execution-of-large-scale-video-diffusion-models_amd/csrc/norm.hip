@@ -185,16 +185,33 @@ static int gn_threads(int nvec, int* krows) {
     return k * nvec;
 }
 
-extern "C" size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G) {
-    const int rows = gn_slab_rows(n_samples, rows_per_sample);
+// `partition_samples` (> 0) fixes the row-slab partition as if the call had that many samples: a sample's statistics
+// are then bit-identical whether it is normalised alone, in a half batch or in the full batch (the slab size otherwise
+// follows the batch size to fill the chip).  0 = use n_samples.
+extern "C" size_t vdx_groupnorm_workspace_part(int n_samples, int rows_per_sample, int C, int G, int partition_samples) {
+    const int rows = gn_slab_rows(partition_samples > 0 ? partition_samples : n_samples, rows_per_sample);
     const size_t nslabs = (rows_per_sample + rows - 1) / rows;
     return ((size_t)n_samples * nslabs * G * 3 + (size_t)n_samples * C * 2) * sizeof(float);
 }
+extern "C" size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G) {
+    return vdx_groupnorm_workspace_part(n_samples, rows_per_sample, C, G, 0);
+}
 
+extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
+                                      const void* gamma, const void* beta, float eps, int G,
+                                      int n_samples, int rows_per_sample, int silu, void* y, int ldy,
+                                      void* workspace, int partition_samples, vdx_stream_t stream);
 extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
                                  const void* gamma, const void* beta, float eps, int G,
                                  int n_samples, int rows_per_sample, int silu, void* y, int ldy,
                                  void* workspace, vdx_stream_t stream) {
+    return vdx_groupnorm_part_f16(x, c1, ldx, x2, c2, ldx2, gamma, beta, eps, G, n_samples, rows_per_sample, silu, y, ldy,
+                                  workspace, 0, stream);
+}
+extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
+                                      const void* gamma, const void* beta, float eps, int G,
+                                      int n_samples, int rows_per_sample, int silu, void* y, int ldy,
+                                      void* workspace, int partition_samples, vdx_stream_t stream) {
     VDX_CHECK(x && gamma && beta && y && workspace, "groupnorm: null pointer");
     const int C = c1 + c2;
     VDX_CHECK(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "groupnorm: c1=%d c2=%d must be multiples of 8", c1, c2);
@@ -207,7 +224,7 @@ extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2,
     p.x = (const f16*)x; p.x2 = (const f16*)x2; p.c1 = c1; p.c2 = c2; p.ldx = ldx; p.ldx2 = ldx2;
     p.C = C; p.G = G; p.cpg = C / G; p.nvec = C / 8;
     p.n_samples = n_samples; p.rps = rows_per_sample;
-    p.slab_rows = gn_slab_rows(n_samples, rows_per_sample);
+    p.slab_rows = gn_slab_rows(partition_samples > 0 ? partition_samples : n_samples, rows_per_sample);
     p.nslabs = (rows_per_sample + p.slab_rows - 1) / p.slab_rows;
     p.partial = (float*)workspace;
     p.ab = p.partial + (size_t)n_samples * p.nslabs * G * 3;

@@ -93,6 +93,7 @@ struct K7P {
     int G;               // pixels per row group = 48 / F
     int gpb;             // row groups per batch item = ceil(S / G)
     int ngroups;         // B * gpb
+    int fmagic;          // ceil(65536 / F): row / F == (row * fmagic) >> 16 for row < 64
     float eps, c;        // LayerNorm eps; softmax scale * log2(e)
 };
 
@@ -318,12 +319,13 @@ struct K7 {
         // ---- P1: heads.  This wave: head hg*NCH + ch of every head group hg.
         f16x4 ohead[NHG][3][4];                                  // [head group][query tile][d tile]: O^T, 4 consecutive d
         // pixel of my query rows / key rows inside the 48-row group (for the block-diagonal mask)
+        // (row / F as a multiply: exact for rows < 64 and every F this kernel accepts)
         int qpix[3], kpix[3][4];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            qpix[i] = (16 * i + n16) / p.F;
+            qpix[i] = ((16 * i + n16) * p.fmagic) >> 16;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) kpix[i][e] = (16 * i + 4 * q4 + e) / p.F;
+            for (int e = 0; e < 4; ++e) kpix[i][e] = ((16 * i + 4 * q4 + e) * p.fmagic) >> 16;
         }
         // 16-row tiles of the group that share no pixel need no score tile at all (F = 16: only the diagonal; F = 24:
         // 7 of 9): bit 3*qt + kt of `need` says query tile qt has a pixel in common with key tile kt (wave-uniform)
@@ -334,6 +336,7 @@ struct K7 {
             for (int b = 0; b < 3; ++b) {
                 const int alo = 16 * a / p.F, ahi = (16 * a + 15) / p.F, blo = 16 * b / p.F, bhi = (16 * b + 15) / p.F;
                 if (!(ahi < blo || bhi < alo)) need |= 1 << (3 * a + b);
+                if (alo == ahi && blo == bhi && alo == blo) need |= 1 << (9 + 3 * a + b);     // both tiles inside ONE pixel: no mask
             }
         need = __builtin_amdgcn_readfirstlane(need);
         // stage 0 has landed for everyone (and X is complete): its fragments open the pipeline
@@ -421,7 +424,8 @@ struct K7 {
                 for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        ok[kt][e] = kpix[kt][e] == qpix[qt];
+                        const bool pure = (need >> (9 + 3 * qt + kt)) & 1;       // wave-uniform
+                        ok[kt][e] = pure || (((need >> (3 * qt + kt)) & 1) && kpix[kt][e] == qpix[qt]);
                         mx = fmaxf(mx, ok[kt][e] ? st[kt][e] : NEG_BIG_K7());
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -680,6 +684,7 @@ extern "C" int vdx_temporal_attn_block_f16(const void* t, int ldt, const void* g
     p.G = 48 / F;
     p.gpb = (HW + p.G - 1) / p.G;
     p.ngroups = B * p.gpb;
+    p.fmagic = (65536 + F - 1) / F;
     p.eps = eps;
     p.c = scale * 1.44269504088896341f;
     hipStream_t st = (hipStream_t)stream;

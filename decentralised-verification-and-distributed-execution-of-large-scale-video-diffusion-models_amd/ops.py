@@ -222,8 +222,10 @@ def gelu(x, out=None):
 _gn_ws: dict = {}
 
 
-def groupnorm(x, gamma, beta, *, groups, n_samples, rows_per_sample, eps, silu_act, x2=None, out=None):
-    """GroupNorm (+SiLU) over rows [n_samples*rows_per_sample][C]; x2 = second concat source."""
+def groupnorm(x, gamma, beta, *, groups, n_samples, rows_per_sample, eps, silu_act, x2=None, out=None, partition_samples=0):
+    """GroupNorm (+SiLU) over rows [n_samples*rows_per_sample][C]; x2 = second concat source.
+    partition_samples: reduce the statistics with the slab partition of a batch of that many samples (bit-stable
+    results for a sample whatever batch it is normalised in; include/vdx.h)."""
     lib = _lib.load()
     r, c1, ldx = _rows(x, "x")
     c2, ldx2 = 0, 0
@@ -242,16 +244,16 @@ def groupnorm(x, gamma, beta, *, groups, n_samples, rows_per_sample, eps, silu_a
     orow, ocol, ldy = _rows(out, "out")
     if orow < M or ocol < Cc:
         raise VdxError("groupnorm: out too small")
-    need = lib.vdx_groupnorm_workspace(n_samples, rows_per_sample, Cc, groups)
+    need = lib.vdx_groupnorm_workspace_part(n_samples, rows_per_sample, Cc, groups, partition_samples)
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
         _gn_ws[key] = ws
-    _lib.check(lib.vdx_groupnorm_f16(_p(x, "x"), c1, ldx, _p(x2, "x2"), c2, ldx2, _p(gamma, "gamma"),
-                                     _p(beta, "beta"), float(eps), groups, n_samples, rows_per_sample,
-                                     int(bool(silu_act)), _p(out, "out"), ldy, ws.data_ptr(), _stream()),
-               "vdx_groupnorm_f16")
+    _lib.check(lib.vdx_groupnorm_part_f16(_p(x, "x"), c1, ldx, _p(x2, "x2"), c2, ldx2, _p(gamma, "gamma"),
+                                          _p(beta, "beta"), float(eps), groups, n_samples, rows_per_sample,
+                                          int(bool(silu_act)), _p(out, "out"), ldy, ws.data_ptr(), partition_samples,
+                                          _stream()), "vdx_groupnorm_f16")
     return out
 
 

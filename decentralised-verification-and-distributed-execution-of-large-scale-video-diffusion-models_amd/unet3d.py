@@ -287,22 +287,47 @@ class UNet3DConditionModel(nn.Module):
     # building blocks (all on row matrices)
     # ------------------------------------------------------------------------------------------
     def _resnet(self, p, x, x2, temb_all, n_img, F, hh, ww):
+        """x may be a one- or two-element LIST [x] / [x, skip] the caller has handed over (its only references): the
+        inputs are then released as soon as the shortcut and the first GroupNorm have consumed them — in the up path
+        the block input AND the skip tensor, 2 x 189 MB at level 0 of a 16-frame chunk, before the convolutions
+        allocate.  (Tensors passed as call arguments stay referenced by the caller's frame until the call returns.)"""
+        if isinstance(x, list):
+            owned = x
+            x, x2 = owned[0], (owned[1] if len(owned) > 1 else None)
+            owned.clear()
         W, g, eps = self.W, self.cfg.norm_num_groups, self.cfg.norm_eps
         M, S = n_img * hh * ww, hh * ww
         off, cout = self._temb_slices[p]
-        h = ops.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=n_img,
-                          rows_per_sample=S, eps=eps, silu_act=True, x2=x2)
-        geo = (n_img, hh, ww, hh, ww, 1, False)
-        h = ops.gemm(h, W[p + ".conv1.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
-                     bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, conv=geo)
-        h = ops.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups=g, n_samples=n_img,
-                          rows_per_sample=S, eps=eps, silu_act=True)
         if p + ".conv_shortcut.weight" in W:
             sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], M=M, a2=x2, bias=W[p + ".conv_shortcut.bias"])
         else:
             if x2 is not None:
                 raise VdxError(f"{p}: concat input needs a conv_shortcut")
             sc = x
+        geo = (n_img, hh, ww, hh, ww, 1, False)
+        B = n_img // F
+        if self.ff_block_bytes and x2 is not None and n_img % 2 == 0 and (B == 1 or B % 2 == 0) and M * cout * 2 > (64 << 20):
+            # memory-lean mode, concat input (up path): the normalised concat [rows][2C] is the widest tensor of the
+            # block; GroupNorm (4-D: statistics per image) -> conv1 runs over the images in two halves, so only half
+            # of it exists at a time.  Same kernels per image, same bits.
+            h = torch.empty((M, cout), dtype=torch.float16, device=x.device)
+            hm, hn = M // 2, n_img // 2
+            for r0 in (0, hm):
+                n1 = ops.groupnorm(x[r0:r0 + hm], W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=hn,
+                                   rows_per_sample=S, eps=eps, silu_act=True, x2=x2[r0:r0 + hm], partition_samples=n_img)
+                ops.gemm(n1, W[p + ".conv1.weight"], M=hm, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
+                         bias2=temb_all[r0 // (F * S):, off:off + cout], rows_per_bias2=F * S,
+                         conv=(hn, hh, ww, hh, ww, 1, False), out=h[r0:r0 + hm])
+                del n1
+            del x, x2
+        else:
+            h = ops.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=n_img,
+                              rows_per_sample=S, eps=eps, silu_act=True, x2=x2)
+            del x, x2
+            h = ops.gemm(h, W[p + ".conv1.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
+                         bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, conv=geo)
+        h = ops.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups=g, n_samples=n_img,
+                          rows_per_sample=S, eps=eps, silu_act=True)
         return ops.gemm(h, W[p + ".conv2.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv2.bias"],
                         residual=sc, conv=geo)
 
@@ -363,7 +388,19 @@ class UNet3DConditionModel(nn.Module):
         if Mp != M:
             ln[M:].zero_()
         ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
-        if S % 8 == 0:
+        if S % 8 == 0 and self.ff_block_bytes and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (64 << 20):
+            # memory-lean mode: images are independent in the self-attention, so q|k, V^T and the attention run over
+            # the images in two halves and only half of those intermediates ([rows][2C] + [C][rows]) is alive at a time
+            o = torch.empty((M, C), dtype=torch.float16, device=x.device)
+            hm, hn = M // 2, n_img // 2
+            for r0 in (0, hm):
+                qk = ops.gemm(ln[r0:r0 + hm], W[b + ".attn1.to_qk.weight"], M=hm)
+                vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln[r0:r0 + hm], M=C)
+                ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=hn, sq=S, skv=S, skv_pad=S, heads=heads, seq_per_kv=1,
+                               scale=scale, out=o[r0:r0 + hm])
+                del qk, vt
+            del ln
+        elif S % 8 == 0:
             qk = ops.gemm(ln, W[b + ".attn1.to_qk.weight"], M=M)
             vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln, M=C)                   # V^T [C][Mp]
             del ln
@@ -525,7 +562,9 @@ class UNet3DConditionModel(nn.Module):
                 skip, sh, sw = skips.pop()
                 if (sh, sw) != (hh, ww):
                     raise VdxError("skip connection resolution mismatch")
-                x = self._resnet(f"{p}.resnets.{j}", x, skip, temb_all, n_img, F, hh, ww)
+                owned = [x, skip]
+                x = skip = None
+                x = self._resnet(f"{p}.resnets.{j}", owned, None, temb_all, n_img, F, hh, ww)
                 x = self._temp_conv(f"{p}.temp_convs.{j}", x, B, F, hh * ww)
                 if t.startswith("CrossAttn"):
                     x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs_pad, n_img, F, hh, ww)

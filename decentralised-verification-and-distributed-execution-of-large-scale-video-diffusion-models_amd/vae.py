@@ -35,6 +35,10 @@ from . import ops, packing
 from ._lib import VdxError
 
 
+GN_PARTITION = 8      # GroupNorm statistics are reduced with the row-slab partition of an 8-frame batch whatever the
+                      # batch: a frame decoded alone (as the reference does, :219-225) has the bits of its batched self
+
+
 @dataclass
 class VaeConfig:
     latent_channels: int = 4
@@ -146,10 +150,10 @@ class AutoencoderKL(nn.Module):
         M, S = n * hh * ww, hh * ww
         geo = (n, hh, ww, hh, ww, 1, False)
         h = ops.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=n, rows_per_sample=S,
-                          eps=1e-6, silu_act=True)
+                          eps=1e-6, silu_act=True, partition_samples=GN_PARTITION)
         h = ops.gemm(h, W[p + ".conv1.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"], conv=geo)
         h = ops.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups=g, n_samples=n, rows_per_sample=S,
-                          eps=1e-6, silu_act=True)
+                          eps=1e-6, silu_act=True, partition_samples=GN_PARTITION)
         sc = x
         if p + ".conv_shortcut.weight" in W:
             sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], M=M, bias=W[p + ".conv_shortcut.bias"])
@@ -161,7 +165,7 @@ class AutoencoderKL(nn.Module):
         if S % 64 != 0:
             raise VdxError(f"AutoencoderKL attention needs h*w % 64 == 0 (got {hh}x{ww})")
         t = ops.groupnorm(x, W[p + ".group_norm.weight"], W[p + ".group_norm.bias"], groups=g, n_samples=n,
-                          rows_per_sample=S, eps=1e-6, silu_act=False)
+                          rows_per_sample=S, eps=1e-6, silu_act=False, partition_samples=GN_PARTITION)
         q = ops.gemm(t, W[p + ".to_q.weight"], M=M, bias=W[p + ".to_q.bias"])
         k = ops.gemm(t, W[p + ".to_k.weight"], M=M, bias=W[p + ".to_k.bias"])
         o = torch.empty((M, C), dtype=torch.float16, device=x.device)
@@ -202,7 +206,7 @@ class AutoencoderKL(nn.Module):
                              conv=(n, hh, ww, 2 * hh, 2 * ww, 1, True))
                 hh, ww = 2 * hh, 2 * ww
         t = ops.groupnorm(x, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], groups=cfg.norm_num_groups,
-                          n_samples=n, rows_per_sample=hh * ww, eps=1e-6, silu_act=True)
+                          n_samples=n, rows_per_sample=hh * ww, eps=1e-6, silu_act=True, partition_samples=GN_PARTITION)
         y = ops.gemm(t, W["decoder.conv_out.weight"], M=n * hh * ww, mode=ops.CONV3X3, bias=W["decoder.conv_out.bias"],
                      conv=(n, hh, ww, hh, ww, 1, False))
         return y, hh, ww

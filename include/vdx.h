@@ -100,6 +100,14 @@ int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, in
                       const void* gamma, const void* beta, float eps, int G,
                       int n_samples, int rows_per_sample, int silu,
                       void* y, int ldy, void* workspace, vdx_stream_t stream);
+/* The same with the row-slab partition of the statistics fixed as for `partition_samples` samples (0 = n_samples): a
+ * sample's result then has the same bits alone, in part of a batch or in the whole batch (callers that split a batch
+ * to save memory, or decode frames one by one like fsdp_chunked_coherent.py:219-225, pass the full batch size). */
+size_t vdx_groupnorm_workspace_part(int n_samples, int rows_per_sample, int C, int G, int partition_samples);
+int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
+                           const void* gamma, const void* beta, float eps, int G,
+                           int n_samples, int rows_per_sample, int silu,
+                           void* y, int ldy, void* workspace, int partition_samples, vdx_stream_t stream);
 /* In-place softmax over the first `cols` columns of each of `rows` rows of x (row stride ld), logits scaled by
  * `scale` in fp32: the probabilities of AutoencoderKL's mid-block attention (one 512-channel head over h*w
  * tokens; diffusers Attention with upcast softmax), reached from fsdp_chunked_coherent.py:223.            */

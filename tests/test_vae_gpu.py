@@ -122,9 +122,10 @@ def test_vae_full_width_properties(gpu):
     a = m.decode(z).sample
     assert a.shape == (3, 3, 192, 256) and torch.isfinite(a).all() and float(a.float().std()) > 0.05
     assert torch.equal(a, m.decode(z).sample)
-    # frames do not mix; the GroupNorm row-slab partition (hence the fp32 summation order of its statistics)
-    # follows the batch size, so a frame decoded alone agrees to rounding, not to the bit
-    assert rel_l2(a[1:2].float(), m.decode(z[1:2]).sample.float()) < 1e-3
+    # frames do not mix, and the GroupNorm statistics are reduced with a fixed row-slab partition: a frame decoded
+    # alone (how the reference decodes, fsdp_chunked_coherent.py:219-225) has the BITS of the same frame in a batch
+    assert torch.equal(a[1:2], m.decode(z[1:2]).sample)
+    assert torch.equal(a[:2], m.decode(z[:2]).sample)
     frames = DistributedVideoDiffuser.decode_frames(
         type("P", (), {"cfg": DiffuserConfig(device=gpu)})(), (z.permute(1, 0, 2, 3)[None].float() * 0.18215), m, batch=2)
     assert len(frames) == 3 and frames[0].shape == (192, 256, 3)

@@ -11,10 +11,14 @@ from vdx.unet3d import UNet3DConditionModel, UNet3DConfig  # noqa: E402
 from vdx.weights import synthetic_state_dict  # noqa: E402
 
 dev = torch.device("cuda:0")
+FRAMES = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+SHARD = len(sys.argv) > 2 and sys.argv[2] == "shard"       # memory-lean sharded mode (world of one: full shards stay resident)
 cfg = UNet3DConfig.zeroscope()
 model = UNet3DConditionModel(cfg)
 model.load_diffusers_state_dict(synthetic_state_dict(cfg, seed=0, device=dev), device=dev)
-lat = torch.randn(2, 4, 24, 72, 128, device=dev, dtype=torch.float16)
+if SHARD:
+    model.shard_(0, 1)
+lat = torch.randn(2, 4, FRAMES, 72, 128, device=dev, dtype=torch.float16)
 ehs = torch.randn(2, 77, 1024, device=dev, dtype=torch.float16)
 torch.cuda.empty_cache()
 base = torch.cuda.memory_allocated()
@@ -32,6 +36,7 @@ def wrap(name):
         out = fn(*a, **k)
         torch.cuda.synchronize()
         rec.append((name, a[0], (before - base) / 2**30, (torch.cuda.max_memory_allocated() - base) / 2**30))
+        a = k = None
         return out
     setattr(model, name, f)
 
