@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-end evidence run on the GPU box: kernel-trace stats + the three PMC passes of the bench command, the default
+# bench line, and the dev tools.  Everything lands under gpurun_out/$1/ ; copy the summaries into profiles/.
+set -o pipefail
+OUT=gpurun_out/${1:-round}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+B="python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-profile > $OUT/stats.log 2>&1
+cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/fetch -- $B > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write -- $B > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma -- $B > $OUT/pmc_mfma.log 2>&1
+python tools/pmc_summary.py $OUT/pmc/fetch $OUT/pmc/write $OUT/pmc/mfma --json $OUT/pmc_current.json > $OUT/pmc_summary.md
+rm -rf $OUT/stats $OUT/pmc
+echo "== bench (default flags)"; python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json
+echo "== tools"; { echo "## tools/block_profile.py"; python tools/block_profile.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/attn_bench.py"; python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/k7_bench.py"; python tools/k7_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/gemm_bench.py"; python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids; } > $OUT/tools.txt
+tail -5 $OUT/tools.txt
