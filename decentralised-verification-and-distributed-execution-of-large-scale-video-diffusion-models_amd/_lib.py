@@ -51,6 +51,11 @@ SIGNATURES = {
     "vdx_temporal_attn_block_wqkv_bytes": (_sz, [_i]),
     "vdx_temporal_attn_block_wo_bytes": (_sz, [_i]),
     "vdx_temporal_attn_block_f16": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "vdx_comm_unique_id": (_i, [_vp]),
+    "vdx_comm_init": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "vdx_comm_destroy": (_i, [_vp]),
+    "vdx_allgather_shard": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "vdx_halo_exchange": (_i, [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp]),
     "vdx_cfg_input_f16": (_i, [_vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "vdx_cfg_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),
     "vdx_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _sz, _vp]),

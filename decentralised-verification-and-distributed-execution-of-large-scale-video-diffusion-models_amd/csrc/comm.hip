@@ -1,0 +1,122 @@
+// comm.hip — the two exchange steps of the path as C-ABI entry points on RCCL:
+//   vdx_allgather_shard   the per-unit parameter all-gather that replaces FSDP's flat-parameter gather
+//                         (fsdp_chunked_coherent.py:63-88; one call per shard unit per step, on a side stream)
+//   vdx_halo_exchange     the post-loop exchange of the overlap frames a neighbour owns (replaces the gather of
+//                         every chunk by every rank, :190-202): one grouped send + receive per neighbour
+// Both enqueue on the stream passed in (the caller's SIDE stream) and return; ordering against the compute stream is the
+// caller's hipEvent hand-off, exactly as for the kernels.  vdx_comm_init is collective (every rank calls it with the id
+// rank 0 made with vdx_comm_unique_id and shared out of band — `vdx/comm.py` broadcasts it through torch.distributed).
+//
+// RCCL is resolved at run time (dlopen/dlsym, re-using the copy PyTorch has already loaded when there is one): the
+// library has no link-time dependency on it, and a box without RCCL can still load every compute entry point.
+#include "vdx_common.h"
+#include <dlfcn.h>
+#include <string.h>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names)
+            if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the copy already in the process (PyTorch's)
+        for (const char* n : names)
+            if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.h) return;
+#define VDX_SYM(field, name) r.field = (decltype(r.field))dlsym(r.h, name)
+        VDX_SYM(GetUniqueId, "ncclGetUniqueId");
+        VDX_SYM(CommInitRank, "ncclCommInitRank");
+        VDX_SYM(CommDestroy, "ncclCommDestroy");
+        VDX_SYM(AllGather, "ncclAllGather");
+        VDX_SYM(Send, "ncclSend");
+        VDX_SYM(Recv, "ncclRecv");
+        VDX_SYM(GroupStart, "ncclGroupStart");
+        VDX_SYM(GroupEnd, "ncclGroupEnd");
+        VDX_SYM(GetErrorString, "ncclGetErrorString");
+#undef VDX_SYM
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Send && r.Recv && r.GroupStart &&
+               r.GroupEnd && r.GetErrorString;
+    });
+    return r;
+}
+
+int nccl_fail(const char* what, ncclResult_t e) {
+    return vdx_fail("%s: RCCL error %d (%s)", what, (int)e, rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
+}
+
+}  // namespace
+
+struct vdx_comm {
+    ncclComm_t comm;
+    int rank, world;
+};
+
+extern "C" int vdx_comm_unique_id(void* id128) {
+    VDX_CHECK(id128, "comm_unique_id: null pointer");
+    VDX_CHECK(rccl().ok, "comm: librccl.so could not be loaded");
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id size");
+    const ncclResult_t e = rccl().GetUniqueId((ncclUniqueId*)id128);
+    return e == ncclSuccess ? 0 : nccl_fail("comm_unique_id", e);
+}
+
+extern "C" int vdx_comm_init(const void* id128, int rank, int world, vdx_comm** out) {
+    VDX_CHECK(id128 && out, "comm_init: null pointer");
+    VDX_CHECK(world > 0 && rank >= 0 && rank < world, "comm_init: rank %d of %d", rank, world);
+    VDX_CHECK(rccl().ok, "comm: librccl.so could not be loaded");
+    const ncclUniqueId id = *(const ncclUniqueId*)id128;
+    ncclComm_t c;
+    const ncclResult_t e = rccl().CommInitRank(&c, world, id, rank);
+    if (e != ncclSuccess) return nccl_fail("comm_init", e);
+    *out = new vdx_comm{c, rank, world};
+    return 0;
+}
+
+extern "C" int vdx_comm_destroy(vdx_comm* c) {
+    if (!c) return 0;
+    const ncclResult_t e = rccl().CommDestroy(c->comm);
+    delete c;
+    return e == ncclSuccess ? 0 : nccl_fail("comm_destroy", e);
+}
+
+extern "C" int vdx_allgather_shard(vdx_comm* c, const void* shard, void* full, size_t shard_bytes, vdx_stream_t side_stream) {
+    VDX_CHECK(c && shard && full, "allgather_shard: null pointer");
+    VDX_CHECK(shard_bytes > 0 && shard_bytes % 16 == 0, "allgather_shard: shard of %zu bytes (must be a positive multiple of 16)", shard_bytes);
+    const ncclResult_t e = rccl().AllGather(shard, full, shard_bytes, ncclUint8, c->comm, (hipStream_t)side_stream);
+    return e == ncclSuccess ? 0 : nccl_fail("allgather_shard", e);
+}
+
+extern "C" int vdx_halo_exchange(vdx_comm* c, const void* send_buf, size_t send_bytes, int send_to, void* recv_buf,
+                                 size_t recv_bytes, int recv_from, vdx_stream_t side_stream) {
+    VDX_CHECK(c, "halo_exchange: null communicator");
+    VDX_CHECK((send_bytes == 0 || (send_buf && send_to >= 0 && send_to < c->world && send_to != c->rank)) &&
+                  (recv_bytes == 0 || (recv_buf && recv_from >= 0 && recv_from < c->world && recv_from != c->rank)),
+              "halo_exchange: bad peer or buffer (send %zu B -> %d, recv %zu B <- %d, rank %d of %d)", send_bytes, send_to,
+              recv_bytes, recv_from, c->rank, c->world);
+    if (send_bytes == 0 && recv_bytes == 0) return 0;
+    hipStream_t st = (hipStream_t)side_stream;
+    ncclResult_t e = rccl().GroupStart();
+    if (e == ncclSuccess && send_bytes) e = rccl().Send(send_buf, send_bytes, ncclUint8, send_to, c->comm, st);
+    if (e == ncclSuccess && recv_bytes) e = rccl().Recv(recv_buf, recv_bytes, ncclUint8, recv_from, c->comm, st);
+    const ncclResult_t e2 = rccl().GroupEnd();
+    if (e != ncclSuccess) return nccl_fail("halo_exchange", e);
+    return e2 == ncclSuccess ? 0 : nccl_fail("halo_exchange", e2);
+}

@@ -181,26 +181,42 @@ class HaloPlan:
         return sum((t.e - t.s) * frame_bytes for t in self.transfers if t.src == rank)
 
 
-def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_stream=None):
+def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_stream=None, comm=None):
     """Send the frames other ranks own, receive the frames this rank owns from the windows other ranks denoised.
     Returns ({(chunk, s, e): tensor (1,C,e-s,H,W)}, event or None): the received pieces are valid on the current
-    stream after `event.wait()` (GPU) or immediately (CPU)."""
+    stream after `event.wait()` (GPU) or immediately (CPU).  `comm` (a `vdx.comm.Comm`): the transfers go through the
+    C-ABI entry point `vdx_halo_exchange` (RCCL send/recv), one call per transfer in the plan's global order."""
     cp = hp.cp
     ref = mine[0]
     _, C, _, H, W = ref.shape
-    got, p2p, keep = {}, [], []
+    got, p2p, keep, native = {}, [], [], []
     for t in hp.transfers:
         if t.src == rank:
             s0 = cp.ranges[t.chunk][0]
             piece = mine[hp.slot_of[t.chunk]][:, :, t.s - s0:t.e - s0].contiguous()
             keep.append(piece)
             p2p.append(dist.P2POp(dist.isend, piece, t.dst))
+            native.append((piece, t.dst, None, -1))
         elif t.dst == rank:
             buf = ref.new_empty((1, C, t.e - t.s, H, W))
             got[(t.chunk, t.s, t.e)] = buf
             p2p.append(dist.P2POp(dist.irecv, buf, t.src))
+            native.append((None, -1, buf, t.src))
     if not p2p:
         return got, None
+    if ref.is_cuda and comm is not None:
+        cur = torch.cuda.current_stream(ref.device)
+        side = side_stream or torch.cuda.Stream(device=ref.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        side.wait_event(ready)
+        for snd, to, rcv, frm in native:
+            comm.halo(snd, to, rcv, frm, side)
+        done = torch.cuda.Event()
+        done.record(side)
+        for t_ in keep + list(got.values()):
+            t_.record_stream(side)
+        return got, done
     if ref.is_cuda:
         cur = torch.cuda.current_stream(ref.device)
         side = side_stream or torch.cuda.Stream(device=ref.device)

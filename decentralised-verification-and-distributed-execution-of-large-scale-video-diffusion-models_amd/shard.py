@@ -33,9 +33,11 @@ def _round_up(x, m):
 
 class ShardedStore:
     def __init__(self, tensors: Dict[str, torch.Tensor], unit_of: Callable[[str], Optional[str]],
-                 schedule: List[str], rank: int, world: int, group=None):
-        """`unit_of(name)` -> unit id, or None for tensors kept replicated (small stem tensors)."""
-        self.rank, self.world, self.group = rank, world, group
+                 schedule: List[str], rank: int, world: int, group=None, comm=None):
+        """`unit_of(name)` -> unit id, or None for tensors kept replicated (small stem tensors).
+        `comm`: a `vdx.comm.Comm` — the gathers then go through the C-ABI (`vdx_allgather_shard`, RCCL) instead of
+        `torch.distributed`."""
+        self.rank, self.world, self.group, self.comm = rank, world, group, comm
         self.schedule = list(schedule)
         self._pos = {u: i for i, u in enumerate(self.schedule)}
         self.replicated: Dict[str, torch.Tensor] = {}
@@ -104,8 +106,10 @@ class ShardedStore:
         shard = self.shards[unit]
 
         def run():
-            if self.world == 1 and not _FORCE_COLLECTIVE():
+            if self.world == 1 and not _FORCE_COLLECTIVE() and self.comm is None:
                 out.copy_(shard)
+            elif self._cuda and self.comm is not None:
+                self.comm.allgather(shard, out, self._side)
             elif self._cuda:
                 dist.all_gather_into_tensor(out, shard, group=self.group)
             else:

@@ -272,12 +272,13 @@ class UNet3DConditionModel(nn.Module):
             return ".".join(parts[:3])
         return None                              # conv_in/out, time embedding, conv_norm_out
 
-    def shard_(self, rank: int, world: int, group=None):
-        """Keep 1/world of every unit on this GPU; gather per unit with prefetch (vdx/shard.py)."""
+    def shard_(self, rank: int, world: int, group=None, comm=None):
+        """Keep 1/world of every unit on this GPU; gather per unit with prefetch (vdx/shard.py).  `comm`: gather through
+        the C-ABI RCCL entry point instead of torch.distributed (vdx/comm.py)."""
         from .shard import ShardedStore
         if not isinstance(self.W, dict):
             raise VdxError("weights are already sharded")
-        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group)
+        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group, comm)
         self.ff_block_bytes = 128 << 20
         if self._device.type == "cuda":
             torch.cuda.empty_cache()

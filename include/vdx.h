@@ -183,6 +183,23 @@ int vdx_blend_finalize_f32(const void* full, const float* weight, float* out, in
  * rows: the decoder's channels-last output rows [n_pixels][ld], RGB in the first 3 columns.            */
 int vdx_rows_to_u8_frames(const void* rows, int ld, size_t n_pixels, void* out_u8, vdx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Exchange steps on RCCL (resolved at run time: no link-time dependency).  One communicator per process / GPU.
+ *   vdx_comm_unique_id : rank 0 fills a 128-byte id and shares it with the other ranks out of band
+ *   vdx_comm_init      : collective; every rank passes the same id
+ *   vdx_allgather_shard: full[r*shard_bytes ..] = rank r's shard — the per-unit parameter gather that stands in for
+ *                        FSDP's flat-parameter all-gather (fsdp_chunked_coherent.py:63-88), once per shard unit per step
+ *   vdx_halo_exchange  : send `send_bytes` to rank `send_to` and receive `recv_bytes` from rank `recv_from` as one group
+ *                        (either side may be 0 bytes) — the overlap frames of the post-loop exchange (:190-202)
+ * Both enqueue on `side_stream` and return; the caller orders them against its compute stream with events. */
+typedef struct vdx_comm vdx_comm;
+int vdx_comm_unique_id(void* id128);
+int vdx_comm_init(const void* id128, int rank, int world, vdx_comm** out);
+int vdx_comm_destroy(vdx_comm* comm);
+int vdx_allgather_shard(vdx_comm* comm, const void* shard, void* full, size_t shard_bytes, vdx_stream_t side_stream);
+int vdx_halo_exchange(vdx_comm* comm, const void* send_buf, size_t send_bytes, int send_to, void* recv_buf,
+                      size_t recv_bytes, int recv_from, vdx_stream_t side_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,41 @@ def unet_xl_chunks_main():
     np.savez_compressed(os.path.join(HERE, "unet_xl_chunks.npz"), **out)
 
 
+CFG1 = dict(T=8, H=32, W=32, steps=3, of_steps=10)     # BASELINE config 1 at its real widths; 3 of its 10 DDIM steps
+
+
+def cfg1_embeddings():
+    g = torch.Generator().manual_seed(51)
+    emb = torch.randn(2, 77, 1024, generator=g).half()
+    return emb[1:], emb[:1]                                             # uncond, cond
+
+
+def cfg1_main():
+    """BASELINE config 1 (Zeroscope 576w shape: 8 frames @256x256 = 32x32 latent, chunk_only strategy) at the FULL
+    width of the network: planner with the chunk_only overlap rule (`chunk_only.py:86`: cs 8, ov 2, windows (0,8),(6,8)),
+    shared noise, the first 3 of the 10-step DDIM schedule per window, gather, ramp blend (`chunk_only.py:65-74,80-150`).
+    The whole flow through `oracle.pipeline_ref.run_video` with the fp32 UNet; stored: the blended latent (fp32)."""
+    from oracle.pipeline_ref import run_video
+    torch.set_num_threads(8)
+    cfg = UNet3DConfig.zeroscope()
+    sd = {k: v.half().float() for k, v in synthetic_state_dict(cfg, seed=1234).items()}
+    m = UNet3DConditionModelRef(cfg).eval()
+    m.load_state_dict(sd)
+    del sd
+    c = CFG1
+    uncond, cond = cfg1_embeddings()
+
+    class FirstSteps(DDIMSchedulerRef):                                  # 10-step schedule, only its first `steps` entries
+        def set_timesteps(self, n, device=None):
+            super().set_timesteps(c["of_steps"], device)
+            self.timesteps = self.timesteps[:c["steps"]]
+
+    lat, (cs, ov, ranges) = run_video(FP32UNetOnHalfIO(m), FirstSteps(), c["T"], 4, c["H"], c["W"], world=1, steps=c["steps"],
+                                      uncond_emb=uncond, cond_emb=cond, chunk_size=0, overlap=4, mode="chunk", rule="third")
+    print("cfg1:", cs, ov, ranges, "lat std", float(lat.std()))
+    np.savez_compressed(os.path.join(HERE, "cfg1_xl.npz"), lat=lat.numpy(), cs=cs, ov=ov, ranges=np.array(ranges))
+
+
 def vae_main():
     """AutoencoderKL decode (tiny widths, same topology): fp32 oracle output of seeded latents + the fp16-CPU
     noise floor of the same computation."""
@@ -209,6 +244,8 @@ if __name__ == "__main__":
         unet_xl_main()
     if what in ("unet_xl_chunks", "all"):
         unet_xl_chunks_main()
+    if what in ("cfg1", "all"):
+        cfg1_main()
     if what in ("vae", "all"):
         vae_main()
     if what in ("clip", "all"):

@@ -101,3 +101,34 @@ def test_unet_through_shard_store_matches_unsharded(gpu):
         got = b(x, 501, encoder_hidden_states=e).sample
         assert torch.equal(got, want)
     assert b.W.gathers <= 3 * len(b.unit_schedule()) + 2
+
+
+@pytest.mark.gpu
+def test_native_rccl_entry_points_world_of_one(gpu):
+    """`vdx_comm_init / vdx_allgather_shard / vdx_halo_exchange` (include/vdx.h; RCCL resolved at run time) with a world
+    of ONE rank — the round trip a single-GPU box allows: the gather reproduces the shard, the shard store gathers its
+    units through the C-ABI on its side stream and the UNet output keeps its bits, an empty halo exchange is a no-op."""
+    import vdx  # noqa: F401
+    from vdx.comm import Comm
+    from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
+    from vdx.weights import synthetic_state_dict
+    comm = Comm.create(Comm.unique_id(), 0, 1)
+    side = torch.cuda.Stream(device=gpu)
+    shard = torch.arange(4096, dtype=torch.float16, device=gpu)
+    full = torch.zeros_like(shard)
+    side.wait_stream(torch.cuda.current_stream())
+    comm.allgather(shard, full, side)
+    comm.halo(None, -1, None, -1, side)
+    side.synchronize()
+    assert torch.equal(full, shard)
+    cfg = UNet3DConfig(block_out_channels=(64, 128, 128, 128), cross_attention_dim=128, transformer_in_heads=2)
+    m = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, seed=5, device=gpu), device=gpu)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 3, 16, 16, generator=g).half().to(gpu)
+    e = torch.randn(2, 77, 128, generator=g).half().to(gpu)
+    want = m(x, 501, encoder_hidden_states=e).sample
+    m.shard_(0, 1, comm=comm)
+    got = m(x, 501, encoder_hidden_states=e).sample
+    assert m.W.gathers > 10 and torch.equal(got, want)
+    torch.cuda.synchronize()
+    comm.destroy()
