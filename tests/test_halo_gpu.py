@@ -12,12 +12,20 @@ pytestmark = pytest.mark.gpu
                                           (32, 3, 0, 4, False), (31, 4, 10, 7, False), (24, 2, 0, 0, True),
                                           (32, 1, 0, 4, False)])
 def test_owned_blend_bits_on_hip_kernels(gpu, T, W, cs, ov, nc):
+    _owned_blend_case(gpu, T, W, cs, ov, nc, 4, 9, 16)
+
+
+def test_owned_blend_bits_at_cfg5_full_size(gpu):
+    """BASELINE config 5 at its real extent: 96 frames of a (4, 72, 128) latent, 8 ranks, 16-frame windows."""
+    _owned_blend_case(gpu, 96, 8, 0, 4, False, 4, 72, 128)
+
+
+def _owned_blend_case(gpu, T, W, cs, ov, nc, C, H, Wd):
     import vdx  # noqa: F401
     from vdx.pipeline import DiffuserConfig, DistributedVideoDiffuser, HaloPlan, blend_owned
     from vdx.planner import plan
     from oracle.pipeline_ref import ramp_blend
     cp = plan(T, W, cs, ov, no_chunking=nc)
-    C, H, Wd = 4, 9, 16
     g = torch.Generator().manual_seed(T + W)
     chunks = {i: (torch.randn(1, C, e - s, H, Wd, generator=g) * 2).half() for i, (s, e) in enumerate(cp.ranges)}
     like = torch.zeros(1, C, T, H, Wd, dtype=torch.float16)
