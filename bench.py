@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--shapes", type=int, default=0, help="also list the top-N GEMM shapes by time (dev aid)")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="N=1 only: run the multi-GPU code path (RCCL init, sharded weights, collectives) with world 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="rehearsal aid: gloo lets several ranks of a real multi-process job share ONE GPU (with --share-gpu); "
+                         "the driver's runs use nccl (= RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal aid: every rank computes on cuda:0")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--ff-block-mb", type=int, default=0, help="diagnostic: feed-forward row-block size of the memory-lean mode")
     ap.add_argument("--resident", action="store_true",
@@ -129,6 +133,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist_mode = world > 1 or args.rehearse_dist
@@ -138,7 +144,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.rehearse_dist:
             os.environ["VDX_SHARD_FORCE_COLLECTIVE"] = "1"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import vdx  # noqa: F401
     from vdx import ops

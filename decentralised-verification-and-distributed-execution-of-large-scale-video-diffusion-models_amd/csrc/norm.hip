@@ -7,19 +7,23 @@
 // (coalesced 16-byte accesses, per-channel scale/shift held in registers).
 #include "vdx_common.h"
 
-// Rows of one sample per block: 128 for the big levels; halved until the grid has >= 1024 blocks so the
-// deep levels (6912 rows in all at level 3) still spread over the 256 CUs instead of ~50-100 blocks.
-static int gn_slab_rows(int n_samples, int rows_per_sample) {
+// Rows of one sample per block: 128 for the big levels, halved until the grid has >= min_blocks blocks so the deep
+// levels (6912 rows in all at level 3) still spread over the 256 CUs.  The statistics pass stops at 256 blocks (one
+// per CU: its per-block reduction epilogue costs as much as ~64 rows of streaming — 21 -> 15 us at level 2), the
+// apply pass, which has no epilogue, at 1024 (28 us at level 2 against 35 with the coarser split).
+static int gn_rows_for(int n_samples, int rows_per_sample, int min_blocks) {
     int rows = 128;
-    while (rows > 8 && (long long)n_samples * ((rows_per_sample + rows - 1) / rows) < 1024) rows >>= 1;
+    while (rows > 8 && (long long)n_samples * ((rows_per_sample + rows - 1) / rows) < min_blocks) rows >>= 1;
     return rows;
 }
+static int gn_stat_rows(int n_samples, int rows_per_sample) { return gn_rows_for(n_samples, rows_per_sample, 256); }
 
 struct GnP {
     const f16 *x, *x2;
     int c1, c2, ldx, ldx2;
     int C, G, cpg, nvec, krows;      // nvec = C/8, krows = rows processed in parallel per block
-    int n_samples, rps, nslabs, slab_rows;   // rps = rows per sample
+    int n_samples, rps, nslabs, slab_rows;   // rps = rows per sample; slabs = row partition of the STATISTICS pass
+    int apply_rows;                          // rows of a sample per block of the apply pass
     float* partial;                  // [n_samples][nslabs][G][3]  (count, mean, M2)
     float* ab;                       // [n_samples][C][2]          (scale, shift)
 };
@@ -56,20 +60,33 @@ __global__ void gn_partial_kernel(const GnP p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) k[j] = s[j] = ss[j] = 0.f;
     const int r_end = min(p.rps, (slab + 1) * p.slab_rows);
+    const size_t base = (size_t)sample * p.rps;
     int cnt = 0;
-    for (int r = slab * p.slab_rows + rsub; r < r_end; r += p.krows, ++cnt) {
-        const f16x8 v = gn_load(p, (size_t)sample * p.rps + r, cv);
-        if (cnt == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) k[j] = (float)v[j];
-        }
+    int r = slab * p.slab_rows + rsub;
+    auto acc = [&](const f16x8 v) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float f = (float)v[j] - k[j];
             s[j] += f;
             ss[j] += f * f;
         }
+    };
+    if (r < r_end) {                                        // the first row sets the shift
+        const f16x8 v = gn_load(p, base + r, cv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = (float)v[j];
+        acc(v);
+        r += p.krows;
+        cnt = 1;
     }
+    // four rows per trip, loads first: one 16-byte load in flight per thread leaves the kernel latency-bound
+    // (3.5 TB/s at level 0); the accumulation order per thread is unchanged (row after row)
+    for (; r + 3 * p.krows < r_end; r += 4 * p.krows, cnt += 4) {
+        const f16x8 v0 = gn_load(p, base + r, cv), v1 = gn_load(p, base + r + p.krows, cv);
+        const f16x8 v2 = gn_load(p, base + r + 2 * p.krows, cv), v3 = gn_load(p, base + r + 3 * p.krows, cv);
+        acc(v0); acc(v1); acc(v2); acc(v3);
+    }
+    for (; r < r_end; r += p.krows, ++cnt) acc(gn_load(p, base + r, cv));
     const int plane = p.krows * p.C;
     const float inv = cnt ? 1.0f / (float)cnt : 0.f;
 #pragma unroll
@@ -118,28 +135,47 @@ __global__ void gn_finalize_kernel(const GnP p, const f16* gamma, const f16* bet
     const int sg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (sg >= p.n_samples * p.G) return;
     const int sample = sg / p.G, g = sg % p.G;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    auto merge_d = [&](double nb, double mb, double m2b) {
-        if (nb == 0.0) return;
-        const double nn = n + nb, d = mb - mean;
-        m2 += m2b + d * d * (n * nb / nn);
-        mean += d * (nb / nn);
-        n = nn;
+    // Slab triples -> one (n, mean, M2) per (sample, group), in double and without a division per slab: with every
+    // mean taken relative to K = the mean of slab 0,
+    //     N = sum n_i,  S1 = sum n_i d_i,  S2 = sum n_i d_i^2,  Q = sum M2_i      (d_i = mean_i - K)
+    //     mean = K + S1 / N,   M2 = Q + S2 - S1^2 / N
+    // which is Chan's merge summed up; d_i is a few standard deviations at most, so nothing cancels at double width.
+    // Fixed order (lane-strided, then a butterfly): bitwise reproducible.
+    const float* src0 = p.partial + (size_t)sample * p.nslabs * 3 * p.G + 3 * g;
+    const size_t stride = (size_t)3 * p.G;
+    const double K = (double)src0[1];
+    double N = 0.0, S1 = 0.0, S2 = 0.0, Q = 0.0;
+    auto add = [&](float nf, float mf, float qf) {
+        const double nn = (double)nf, d = (double)mf - K;
+        N += nn;
+        S1 += nn * d;
+        S2 += nn * d * d;
+        Q += (double)qf;
     };
-    for (int i = lane; i < p.nslabs; i += 64) {
-        const float* src = p.partial + ((size_t)sample * p.nslabs + i) * 3 * p.G + 3 * g;
-        merge_d((double)src[0], (double)src[1], (double)src[2]);
+    int i = lane;
+    for (; i + 192 < p.nslabs; i += 256) {                  // four slabs per trip, their loads in flight together
+        const float* a0 = src0 + (size_t)i * stride;
+        const float* a1 = a0 + 64 * stride;
+        const float* a2 = a1 + 64 * stride;
+        const float* a3 = a2 + 64 * stride;
+        const float n0 = a0[0], m0 = a0[1], q0 = a0[2], n1 = a1[0], m1 = a1[1], q1 = a1[2];
+        const float n2 = a2[0], m2_ = a2[1], q2 = a2[2], n3 = a3[0], m3 = a3[1], q3 = a3[2];
+        add(n0, m0, q0); add(n1, m1, q1); add(n2, m2_, q2); add(n3, m3, q3);
+    }
+    for (; i < p.nslabs; i += 64) {
+        const float* a0 = src0 + (size_t)i * stride;
+        add(a0[0], a0[1], a0[2]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {                      // fixed butterfly order: reproducible
-        const double nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(m2, o, 64);
-        // both partners must end with the same value: merge symmetrically (lower lane's triple first)
+    for (int o = 32; o > 0; o >>= 1) {                      // both partners add (low, high) in the same order
+        const double Nb = __shfl_xor(N, o, 64), S1b = __shfl_xor(S1, o, 64), S2b = __shfl_xor(S2, o, 64), Qb = __shfl_xor(Q, o, 64);
         const bool low = (lane & o) == 0;
-        const double na = low ? n : nb, ma = low ? mean : mb, m2a = low ? m2 : m2b;
-        const double nc = low ? nb : n, mc = low ? mb : mean, m2c = low ? m2b : m2;
-        n = na; mean = ma; m2 = m2a;
-        merge_d(nc, mc, m2c);
+        N = low ? N + Nb : Nb + N;
+        S1 = low ? S1 + S1b : S1b + S1;
+        S2 = low ? S2 + S2b : S2b + S2;
+        Q = low ? Q + Qb : Qb + Q;
     }
+    const double n = N, mean = N > 0.0 ? K + S1 / N : 0.0, m2 = N > 0.0 ? Q + S2 - S1 * S1 / N : 0.0;
     double var = n > 0.0 ? m2 / n : 0.0;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -164,9 +200,10 @@ __global__ void gn_apply_kernel(const GnP p, f16* y, int ldy) {
         a[j] = ab[2 * j];
         b[j] = ab[2 * j + 1];
     }
-    const int r_end = min(p.rps, (slab + 1) * p.slab_rows);
-    for (int r = slab * p.slab_rows + rsub; r < r_end; r += p.krows) {
-        const size_t row = (size_t)sample * p.rps + r;
+    const int r_end = min(p.rps, (slab + 1) * p.apply_rows);
+    const size_t base = (size_t)sample * p.rps;
+    for (int r = slab * p.apply_rows + rsub; r < r_end; r += p.krows) {
+        const size_t row = base + r;
         const f16x8 v = gn_load(p, row, cv);
         f16x8 o;
 #pragma unroll
@@ -189,7 +226,7 @@ static int gn_threads(int nvec, int* krows) {
 // are then bit-identical whether it is normalised alone, in a half batch or in the full batch (the slab size otherwise
 // follows the batch size to fill the chip).  0 = use n_samples.
 extern "C" size_t vdx_groupnorm_workspace_part(int n_samples, int rows_per_sample, int C, int G, int partition_samples) {
-    const int rows = gn_slab_rows(partition_samples > 0 ? partition_samples : n_samples, rows_per_sample);
+    const int rows = gn_stat_rows(partition_samples > 0 ? partition_samples : n_samples, rows_per_sample);
     const size_t nslabs = (rows_per_sample + rows - 1) / rows;
     return ((size_t)n_samples * nslabs * G * 3 + (size_t)n_samples * C * 2) * sizeof(float);
 }
@@ -224,7 +261,8 @@ extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void
     p.x = (const f16*)x; p.x2 = (const f16*)x2; p.c1 = c1; p.c2 = c2; p.ldx = ldx; p.ldx2 = ldx2;
     p.C = C; p.G = G; p.cpg = C / G; p.nvec = C / 8;
     p.n_samples = n_samples; p.rps = rows_per_sample;
-    p.slab_rows = gn_slab_rows(partition_samples > 0 ? partition_samples : n_samples, rows_per_sample);
+    p.slab_rows = gn_stat_rows(partition_samples > 0 ? partition_samples : n_samples, rows_per_sample);
+    p.apply_rows = gn_rows_for(n_samples, rows_per_sample, 1024);
     p.nslabs = (rows_per_sample + p.slab_rows - 1) / p.slab_rows;
     p.partial = (float*)workspace;
     p.ab = p.partial + (size_t)n_samples * p.nslabs * G * 3;
@@ -234,10 +272,11 @@ extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void
     hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), (2 * (size_t)p.krows * C + p.krows + 2 * (size_t)G * p.krows) * sizeof(float), st, p);
     const int nsg = n_samples * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, st, p, (const f16*)gamma, (const f16*)beta, eps);
+    dim3 agrid((rows_per_sample + p.apply_rows - 1) / p.apply_rows, n_samples);
     if (silu)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(nt), 0, st, p, (f16*)y, ldy);
+        hipLaunchKernelGGL(gn_apply_kernel<true>, agrid, dim3(nt), 0, st, p, (f16*)y, ldy);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(nt), 0, st, p, (f16*)y, ldy);
+        hipLaunchKernelGGL(gn_apply_kernel<false>, agrid, dim3(nt), 0, st, p, (f16*)y, ldy);
     return vdx_launch_status("vdx_groupnorm_f16");
 }
 
@@ -289,77 +328,110 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, int ldx, c
     }
 }
 
-// Packed variant for the level-0/1 widths (C = 320 / 640: 40 / 80 vectors of 8 per row): a wave takes
-// R = 8 / 4 rows = 320 vectors = five fully used 1 KB wave loads instead of one row on 40 of its 64 lanes
-// (the one-wave-per-row kernel reaches 3.7 TB/s at C = 320).  Flat vector v = 64*j + lane belongs to row v / nvec;
-// the per-row sums are R wave reductions of masked partials — the same number of reductions per row as before.
-template <int R>
-__global__ __launch_bounds__(256) void layernorm_packed_kernel(const f16* x, int ldx, const f16* gamma, const f16* beta,
-                                                                float eps, int M, int C, f16* y, int ldy) {
-    constexpr int NL = 5;
+// Row-group variant for widths C = LPR * NL * 8 (320 = 8 x 5, 640 = 16 x 5, 1280 = 32 x 5, 512 = 16 x 4, ...): LPR
+// adjacent lanes share a row (lane sub-index s holds column vectors s, s + LPR, ...: every wave load covers 64 / LPR
+// rows in pieces of LPR x 16 contiguous bytes), so ONE cross-lane reduction over LPR lanes (DPP adds up to 16 lanes)
+// serves all the rows of the wave at once — the one-row-per-wave kernel spends 2 x 6 shuffles per row on 40 of its 64
+// lanes at C = 320.  A wave walks row groups with a grid stride and loads the next group before it reduces the
+// current one; gamma / beta stay in registers.  Two-pass variance (mean, then sum of squared deviations).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int LPR>
+__device__ __forceinline__ float lanes_sum(float v) {
+    v = dpp_add<0xB1>(v);                          // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);                          // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);                         // row_half_mirror: the other quad of the 8 (all four lanes hold its sum)
+    if (LPR >= 16) v = dpp_add<0x140>(v);          // row_mirror: the other 8 of the 16
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int LPR, int NL>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const f16* __restrict__ x, int ldx, const f16* __restrict__ gamma,
+                                                              const f16* __restrict__ beta, float eps, int M,
+                                                              f16* __restrict__ y, int ldy, int ngroups) {
+    constexpr int RW = 64 / LPR;
+    constexpr float inv_c = 1.0f / (float)(LPR * NL * 8);
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-    if (row0 >= M) return;
-    const int nvec = C >> 3;           // R * nvec == 320
-    f16x8 v[NL];
-    int rr[NL], cc[NL];
-    float s[NL];
+    const int sub = lane % LPR, rw = lane / LPR;
+    const int nwaves = gridDim.x * 4;
+    int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grp >= ngroups) return;
+    f16x8 g[NL], b[NL], v[NL], nv[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-        const int flat = 64 * j + lane;
-        rr[j] = flat / nvec;
-        cc[j] = flat - rr[j] * nvec;
-        const bool ok = row0 + rr[j] < M;
-        s[j] = 0.f;
-        if (ok) {
-            v[j] = *(const f16x8*)(x + (size_t)(row0 + rr[j]) * ldx + cc[j] * 8);
+        g[j] = *(const f16x8*)(gamma + (sub + LPR * j) * 8);
+        b[j] = *(const f16x8*)(beta + (sub + LPR * j) * 8);
+    }
+    auto fetch = [&](int gi, f16x8* dst) {
+        const int row = gi * RW + rw;
+        if (row < M) {
+            const f16* xr = x + (size_t)row * ldx + sub * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s[j] += (float)v[j][e];
+            for (int j = 0; j < NL; ++j) dst[j] = *(const f16x8*)(xr + LPR * 8 * j);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[j][e] = (f16)0.f;
+            for (int j = 0; j < NL; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[j][e] = (f16)0.f;
         }
-    }
-    float mean[NL], rstd[NL];
+    };
+    fetch(grp, v);
+    while (true) {
+        const int nxt = grp + nwaves;
+        if (nxt < ngroups) fetch(nxt, nv);
+        float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        float t = 0.f;
+        for (int j = 0; j < NL; ++j)
 #pragma unroll
-        for (int j = 0; j < NL; ++j) t += rr[j] == r ? s[j] : 0.f;
-        const float m = wave_sum(t) / (float)C;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) mean[j] = rr[j] == r ? m : mean[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
+            for (int e = 0; e < 8; ++e) s += (float)v[j][e];
+        const float mean = lanes_sum<LPR>(s) * inv_c;
         float q = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float d = (float)v[j][e] - mean[j];
-            q += d * d;
+        for (int j = 0; j < NL; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)v[j][e] - mean;
+                q += d * d;
+            }
+        const float rstd = rsqrtf(lanes_sum<LPR>(q) * inv_c + eps);
+        const int row = grp * RW + rw;
+        if (row < M) {
+            f16* yr = y + (size_t)row * ldy + sub * 8;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                // keep gamma / beta PACKED across the loop: without this the fp32 conversions are hoisted out of it
+                // and the kernel needs 192 registers (two waves per SIMD)
+                asm volatile("" : "+v"(g[j]), "+v"(b[j]));
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)v[j][e] - mean) * rstd * (float)g[j][e] + (float)b[j][e]);
+                *(f16x8*)(yr + LPR * 8 * j) = o;
+            }
         }
-        s[j] = q;
+        if (nxt >= ngroups) break;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) v[j] = nv[j];
+        grp = nxt;
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) t += rr[j] == r ? s[j] : 0.f;
-        const float rs = rsqrtf(wave_sum(t) / (float)C + eps);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) rstd[j] = rr[j] == r ? rs : rstd[j];
+}
+
+template <int LPR>
+static bool ln_rows_launch(int nl, dim3 grid, hipStream_t st, const f16* x, int ldx, const f16* gamma, const f16* beta, float eps,
+                           int M, f16* y, int ldy, int ngroups) {
+#define LNR(NL) hipLaunchKernelGGL((layernorm_rows_kernel<LPR, NL>), grid, dim3(256), 0, st, x, ldx, gamma, beta, eps, M, y, ldy, ngroups)
+    switch (nl) {
+        case 1: LNR(1); return true;
+        case 2: LNR(2); return true;
+        case 3: LNR(3); return true;
+        case 4: LNR(4); return true;
+        case 5: LNR(5); return true;
+        default: return false;
     }
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        if (row0 + rr[j] < M) {
-            const f16x8 g = *(const f16x8*)(gamma + cc[j] * 8);
-            const f16x8 b = *(const f16x8*)(beta + cc[j] * 8);
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)v[j][e] - mean[j]) * rstd[j] * (float)g[e] + (float)b[e]);
-            *(f16x8*)(y + (size_t)(row0 + rr[j]) * ldy + cc[j] * 8) = o;
-        }
-    }
+#undef LNR
 }
 
 extern "C" int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* beta, float eps,
@@ -369,14 +441,19 @@ extern "C" int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, cons
     const int nv = (C / 8 + 63) / 64;
     VDX_CHECK(nv <= 4, "layernorm: C=%d too wide (max 2048)", C);
     hipStream_t st = (hipStream_t)stream;
-    if (C == 320 || C == 640) {       // packed: R rows per wave, 4 waves per block (measured: 3.75 -> 4.0 TB/s at 320; no gain at 1280)
-        const int R = 2560 / C;
-        dim3 pgrid((M + 4 * R - 1) / (4 * R)), pblock(256);
-#define LNP_LAUNCH(RR) hipLaunchKernelGGL(layernorm_packed_kernel<RR>, pgrid, pblock, 0, st, (const f16*)x, ldx, (const f16*)gamma, (const f16*)beta, eps, M, C, (f16*)y, ldy)
-        if (R == 8) LNP_LAUNCH(8);
-        else LNP_LAUNCH(4);
-#undef LNP_LAUNCH
-        return vdx_launch_status("vdx_layernorm_f16");
+    const int nvec = C / 8;
+    for (int lpr = 8; lpr <= 64; lpr <<= 1) {             // C = lpr * nl * 8 with nl <= 5: the row-group kernel
+        if (nvec % lpr || nvec / lpr > 5) continue;
+        const int ngroups = (M + 64 / lpr - 1) / (64 / lpr);
+        const int want = (ngroups + 3) / 4;
+        dim3 rgrid(want < 2048 ? want : 2048);            // <= 8 blocks per CU; a wave then walks >= 1 row groups
+        bool ok = false;
+        const f16 *xx = (const f16*)x, *gg = (const f16*)gamma, *bb = (const f16*)beta;
+        if (lpr == 8) ok = ln_rows_launch<8>(nvec / lpr, rgrid, st, xx, ldx, gg, bb, eps, M, (f16*)y, ldy, ngroups);
+        else if (lpr == 16) ok = ln_rows_launch<16>(nvec / lpr, rgrid, st, xx, ldx, gg, bb, eps, M, (f16*)y, ldy, ngroups);
+        else if (lpr == 32) ok = ln_rows_launch<32>(nvec / lpr, rgrid, st, xx, ldx, gg, bb, eps, M, (f16*)y, ldy, ngroups);
+        else ok = ln_rows_launch<64>(nvec / lpr, rgrid, st, xx, ldx, gg, bb, eps, M, (f16*)y, ldy, ngroups);
+        if (ok) return vdx_launch_status("vdx_layernorm_f16");
     }
     dim3 grid((M + 3) / 4), block(256);
 #define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, (const f16*)x, ldx, (const f16*)gamma, (const f16*)beta, eps, M, C, (f16*)y, ldy)

@@ -110,7 +110,7 @@ class ShardedStore:
                 out.copy_(shard)
             elif self._cuda and self.comm is not None:
                 self.comm.allgather(shard, out, self._side)
-            elif self._cuda:
+            elif self._cuda and dist.get_backend(self.group) != "gloo":
                 dist.all_gather_into_tensor(out, shard, group=self.group)
             else:
                 dist.all_gather(list(out.chunk(self.world)), shard, group=self.group)

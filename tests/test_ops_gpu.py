@@ -285,7 +285,9 @@ def test_groupnorm_large_mean(gpu, ns, rps, C, mean, std):
     close(out, ref, tol=4e-3)
 
 
-@pytest.mark.parametrize("M,C", [(37, 64), (100, 320), (9, 1280), (5, 512), (4099, 320), (131, 640), (64, 1280)])
+@pytest.mark.parametrize("M,C", [(37, 64), (100, 320), (9, 1280), (5, 512), (4099, 320), (131, 640), (64, 1280),
+                                 (70001, 320), (40003, 640), (20011, 1280),      # a wave walks several row groups
+                                 (1000, 1024), (777, 768), (3, 2048), (50, 96), (33, 32)])
 def test_layernorm(gpu, M, C):
     ops, _ = _ops()
     g = torch.Generator().manual_seed(M + C)
