@@ -268,7 +268,8 @@ static int launch(const GemmP& p, hipStream_t st) {
 
 // Kernel choice.  `force` (vdx_gemm_args.epilogue bits 8..11, a testing/tuning knob) pins a
 // variant: 1 = 128x128 two-stage, 2 = 256x320 two-stage (K-step 64), 3 = 256x320 four-stage ring
-// (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 5 = 256x64, 6 = variant 2 without the
+// (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 8 = 128x320 four-stage ring with eight
+// 32x160 waves, 5 = 256x64, 6 = variant 2 without the
 // split staging roles (every wave issues its share of both operands at the top of the K tile); 7 (handled in
 // vdx_gemm_f16) = the weights-stationary short-K kernels of gemm_ws.hip.
 template <int MODE, bool GEGLU>
@@ -278,8 +279,9 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
         // Channel widths of this UNet are multiples of 320: the 320-wide tiles (64x160 per wave)
         // halve LDS/L2 bytes per MFMA against 128x128.  Measured per shape (tools/gemm_bench.py,
         // profiles/r01_gemm_variants.txt): the 256x320 two-stage K-64 kernel wins whenever its grid
-        // fills the chip; for the small-M level-3 shapes the 128x320 kernel (twice the blocks)
-        // wins; K-32 rings lose to K-64 on every large shape.
+        // fills the chip; for the small-M level-3 shapes the 128x320 tile (twice the blocks) wins, as
+        // eight 32x160 waves on a four-stage ring (variant 8: 5-8 % over the four-wave two-stage variant 4,
+        // profiles/r02_tools.txt); K-32 rings lose to K-64 on every large shape.
         // Widths that are not multiples of 320 (transformer_in: 512/1536/4096) still take the 320-wide
         // tile when the masked tail wastes < 25 % of the last column of tiles.
         const int nt320 = (p.N + 319) / 320;
@@ -287,7 +289,7 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
         const long long t256 = (long long)((p.M + 255) / 256) * nt320;
         const long long t128 = (long long)((p.M + 127) / 128) * nt320;
         if (fits && t256 >= 192) v = 2;
-        else if (fits && t128 >= 160) v = 4;
+        else if (fits && t128 >= 160) v = 8;
         else v = p.N > 64 ? 1 : 5;
     }
     switch (v) {
@@ -296,6 +298,7 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
         case 6: return launch<256, 320, 4, 2, MODE, GEGLU, false>(p, st);
         case 3: return vdx_gemm_ring_launch(p, MODE, GEGLU, 0, st);
         case 4: return vdx_gemm_ring_launch(p, MODE, GEGLU, 1, st);
+        case 8: return vdx_gemm_ring_launch(p, MODE, GEGLU, 2, st);
         case 5: return launch<256, 64, 4, 1, MODE, GEGLU>(p, st);
     }
     return vdx_fail("gemm: unknown kernel variant %d", v);

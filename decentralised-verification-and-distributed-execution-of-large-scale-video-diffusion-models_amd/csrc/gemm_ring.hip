@@ -19,20 +19,24 @@
 namespace {
 
 constexpr int BN = 320;
-constexpr int TM = 4, TN = 10;
+constexpr int TN = 10;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// WMB = waves along M (4: 256x320 tile, 8 waves; 2: 128x320 tile, 4 waves), NS = ring stages.
-//   <4, 4>: 144 KB LDS, one block per CU, two stages of DMA in flight across each barrier.
-//   <2, 2>: 56 KB LDS, TWO blocks per CU — one block's prologue/epilogue (short-K Linear layers,
-//           the erf-heavy GEGLU epilogue) overlaps the other's MFMA phase.
-template <int WMB, int NS, int MODE, bool GEGLU>
+// WMB = waves along M, RPW = rows per wave (a wave's tile is RPW x 160), NS = ring stages.
+//   <4, 64, 4>: 256x320 tile, 8 waves, 144 KB LDS, one block per CU, two stages of DMA in flight across each barrier.
+//   <2, 64, 2>: 128x320 tile, 4 waves, 56 KB LDS, TWO blocks per CU — one block's prologue/epilogue (short-K Linear
+//               layers, the erf-heavy GEGLU epilogue) overlaps the other's MFMA phase.
+//   <4, 32, 4>: 128x320 tile, EIGHT waves of 32x160, 112 KB LDS, four-stage ring: the level-3 shapes (M = 6912:
+//               216 tiles of 128x320 on 256 CUs, one block per CU whatever the kernel) get two waves per SIMD and
+//               two stages of DMA in flight instead of one wave per SIMD behind a vmcnt(0) drain.
+template <int WMB, int RPW, int NS, int MODE, bool GEGLU>
 __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
-    constexpr int BM = WMB * 64, NW = WMB * 2;
+    constexpr int BM = WMB * RPW, NW = WMB * 2, TM = RPW / 16;
+    constexpr int NA = BM / 16 / NW;               // A pieces per wave (2, or 1 for the 32-row waves)
     constexpr int STAGE = (BM + BN) * 64;          // 32 K-elements (64 B) per row
     constexpr int NB = (20 + NW - 1) / NW;         // B pieces per wave (the last may be absent)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,11 +54,11 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
     // issues A pieces w, w+NW and B pieces w, w+NW, ... (< 20).
     const int drow = lane >> 2, dslot = lane & 3;
     const int csw = (dslot ^ (3 * ((drow >> 2) & 1))) * 8;      // element offset of my data chunk
-    size_t a_off[2], a_off2[2];
-    int a_y[2], a_x[2];
-    bool a_ok[2];
+    size_t a_off[NA], a_off2[NA];
+    int a_y[NA], a_x[NA];
+    bool a_ok[NA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const int m = m0 + 16 * (wave + NW * i) + drow;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
         if (MODE == 0) {
             const bool first = kc < p.c1;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const f16* src = first ? p.a + a_off[i] + kc : p.a2 + a_off2[i] + (kc - p.c1);
                 __builtin_amdgcn_global_load_lds((gptr_t)(a_ok[i] ? src + csw : zp), (lptr_t)(sa + i * NW * 1024), 16, 0, 0);
             }
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int hlim = p.h_in << p.ups, wlim = p.w_in << p.ups;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 int y = a_y[i] + ky, x = a_x[i] + kx;
                 const bool ok = a_ok[i] && (unsigned)y < (unsigned)hlim && (unsigned)x < (unsigned)wlim;
                 y >>= p.ups;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int f = a_y[i] + tap - 1;
                 const bool ok = a_ok[i] && (unsigned)f < (unsigned)p.frames;
                 const f16* src = p.a + (a_off[i] + (size_t)((tap - 1) * p.hw)) * p.lda + kc + csw;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
     const int nk = p.K >> 5;
     const int frow = lane & 15, fq = lane >> 4;
     const int coff = (fq ^ (3 * ((frow >> 2) & 1))) << 4;        // my 16-byte slot inside a 64-byte row
-    const int a_rd = (wm * 64 + frow) * 64 + coff;
+    const int a_rd = (wm * RPW + frow) * 64 + coff;
     const int b_rd = BM * 64 + (wn * 160 + frow) * 64 + coff;
 
     int issued = 0;
@@ -165,9 +169,9 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
         if (NS == 2) {
             wait_vmcnt<0>();
         } else if (has_last) {
-            if (ahead == 2) wait_vmcnt<2 * (NB + 2)>(); else if (ahead == 1) wait_vmcnt<NB + 2>(); else wait_vmcnt<0>();
+            if (ahead == 2) wait_vmcnt<2 * (NB + NA)>(); else if (ahead == 1) wait_vmcnt<NB + NA>(); else wait_vmcnt<0>();
         } else {
-            if (ahead == 2) wait_vmcnt<2 * (NB + 1)>(); else if (ahead == 1) wait_vmcnt<NB + 1>(); else wait_vmcnt<0>();
+            if (ahead == 2) wait_vmcnt<2 * (NB - 1 + NA)>(); else if (ahead == 1) wait_vmcnt<NB - 1 + NA>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         if (issued < nk) {
@@ -191,14 +195,14 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][g * 5 + j], 0, 0, 0);
         }
     }
-    gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * 64, n0 + wn * 160, frow, fq, gelu);
+    gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * RPW, n0 + wn * 160, frow, fq, gelu);
 }
 
-template <int WMB, int NS, int MODE, bool GEGLU>
+template <int WMB, int RPW, int NS, int MODE, bool GEGLU>
 int launch_ring(const GemmP& p, hipStream_t st) {
-    constexpr int BM = WMB * 64;
+    constexpr int BM = WMB * RPW;
     constexpr int lds = NS * (BM + BN) * 64 + (GEGLU ? GELU_TAB_BYTES : 0);
-    auto kern = gemm_ring_kernel<WMB, NS, MODE, GEGLU>;
+    auto kern = gemm_ring_kernel<WMB, RPW, NS, MODE, GEGLU>;
     // one-time LDS opt-in; a function-local static is initialised exactly once even under concurrent callers
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
@@ -212,16 +216,18 @@ int launch_ring(const GemmP& p, hipStream_t st) {
 
 }  // namespace
 
-template <int WMB, int NS>
+template <int WMB, int RPW, int NS>
 static int dispatch(const GemmP& p, int mode, bool geglu, hipStream_t st) {
-    if (geglu) return launch_ring<WMB, NS, 0, true>(p, st);
+    if (geglu) return launch_ring<WMB, RPW, NS, 0, true>(p, st);
     switch (mode) {
-        case VDX_GEMM_PLAIN: return launch_ring<WMB, NS, 0, false>(p, st);
-        case VDX_GEMM_CONV3X3: return launch_ring<WMB, NS, 1, false>(p, st);
-        default: return launch_ring<WMB, NS, 2, false>(p, st);
+        case VDX_GEMM_PLAIN: return launch_ring<WMB, RPW, NS, 0, false>(p, st);
+        case VDX_GEMM_CONV3X3: return launch_ring<WMB, RPW, NS, 1, false>(p, st);
+        default: return launch_ring<WMB, RPW, NS, 2, false>(p, st);
     }
 }
 
 int vdx_gemm_ring_launch(const GemmP& p, int mode, bool geglu, int variant, hipStream_t st) {
-    return variant == 0 ? dispatch<4, 4>(p, mode, geglu, st) : dispatch<2, 2>(p, mode, geglu, st);
+    if (variant == 0) return dispatch<4, 64, 4>(p, mode, geglu, st);
+    if (variant == 1) return dispatch<2, 64, 2>(p, mode, geglu, st);
+    return dispatch<4, 32, 4>(p, mode, geglu, st);
 }

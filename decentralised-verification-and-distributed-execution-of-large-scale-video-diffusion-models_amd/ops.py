@@ -145,14 +145,14 @@ def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: in
         if fits and t256 >= 192:
             v = 2
         elif fits and t128 >= 160:
-            v = 4
+            v = 8
         else:
             v = 1 if N > 64 else 5
     tail = f"{0 if geglu else mode}, {'true' if geglu else 'false'}"
     split = {1: ", false>", 2: ", true>" if (mode != PLAIN and not geglu) else ", false>", 5: ", false>",
              6: ", false>"}.get(v, ">")   # gemm_kernel's SPLIT flag
-    return {1: "gemm_kernel<128, 128, 2, 2, ", 2: "gemm_kernel<256, 320, 4, 2, ", 3: "gemm_ring_kernel<4, 4, ",
-            4: "gemm_ring_kernel<2, 2, ", 5: "gemm_kernel<256, 64, 4, 1, ", 6: "gemm_kernel<256, 320, 4, 2, "}[v] + tail + split
+    return {1: "gemm_kernel<128, 128, 2, 2, ", 2: "gemm_kernel<256, 320, 4, 2, ", 3: "gemm_ring_kernel<4, 64, 4, ",
+            4: "gemm_ring_kernel<2, 64, 2, ", 8: "gemm_ring_kernel<4, 32, 4, ", 5: "gemm_kernel<256, 64, 4, 1, ", 6: "gemm_kernel<256, 320, 4, 2, "}[v] + tail + split
 
 
 def conv_in(x, w, bias, out=None):

@@ -59,7 +59,7 @@ def test_gemm_plain(gpu, M, N, K, flags):
     close(out, ref)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 6])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 6, 8])
 def test_gemm_320_wide_kernels_all_modes(gpu, variant):
     """The 320-wide kernels in every gather mode, with M tails: variant 2 = 256x320 two-stage,
     3 = 256x320 four-stage ring (counted vmcnt), 4 = 128x320 two blocks per CU, 0 = automatic choice."""
@@ -148,7 +148,7 @@ def test_gemm_weights_stationary(gpu, M, N, K, flags):
     assert torch.equal(out, ops.gemm(a_view, d(w), M=M, bias=bias, residual=res, variant=2))
 
 
-@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("variant", [2, 4, 8])
 @pytest.mark.parametrize("M,N", [(3000, 1600), (700, 2880), (5000, 4160)])
 def test_gemm_wide_n_panel_order(gpu, variant, M, N):
     """More than four 320-wide column tiles: tiles are walked in column panels of 4 (gemm_tile_of); 5, 9 and 13 tiles
