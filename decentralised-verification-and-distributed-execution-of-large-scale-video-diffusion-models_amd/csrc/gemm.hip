@@ -286,11 +286,21 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
         // tile when the masked tail wastes < 25 % of the last column of tiles.
         const int nt320 = (p.N + 319) / 320;
         const bool fits = nt320 * 320 * 4 <= p.N * 5 && p.M >= 1024;   // (swapped V^T products have M = C)
-        const long long t256 = (long long)((p.M + 255) / 256) * nt320;
-        const long long t128 = (long long)((p.M + 127) / 128) * nt320;
-        if (fits && t256 >= 192) v = 2;
-        else if (fits && t128 >= 160) v = 8;
-        else v = p.N > 64 ? 1 : 5;
+        if (!fits) {
+            v = p.N > 64 ? 1 : 5;
+        } else {
+            // One block per CU for all three candidates, so a launch costs (rounds of 256 tiles) x (time of one tile).
+            // Tile times relative to the 256x320 tile, fitted to tools/gemm_bench.py at 24 / 16 / 12 frames
+            // (profiles/r02_tools.txt): 128x320 as eight 32x160 waves 0.8 (half the work at 62 % of the efficiency),
+            // 128x128 0.3 (a fifth of the work at 67 %).  The 16-frame windows of BASELINE cfg4/5 are where this
+            // matters: M = 18 432 rows at level 2 is 288 tiles of 256x320 = two rounds for 1.125 rounds of work, and
+            // the 128x128 kernel (5.6 rounds of small tiles) is 10-16 % faster there; level 3 at 16 / 12 frames likewise.
+            const long long t256 = (long long)((p.M + 255) / 256) * nt320;
+            const long long t128 = (long long)((p.M + 127) / 128) * nt320;
+            const long long t1 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+            const long long c2 = 10 * ((t256 + 255) / 256), c8 = 8 * ((t128 + 255) / 256), c1 = 3 * ((t1 + 255) / 256);
+            v = (c2 <= c8 && c2 <= c1) ? 2 : (c8 <= c1 ? 8 : 1);
+        }
     }
     switch (v) {
         case 1: return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);

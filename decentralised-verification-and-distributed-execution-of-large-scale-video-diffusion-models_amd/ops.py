@@ -140,14 +140,14 @@ def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: in
     if v == 0:
         nt320 = (N + 319) // 320
         fits = nt320 * 320 * 4 <= N * 5 and M >= 1024
-        t256 = ((M + 255) // 256) * nt320
-        t128 = ((M + 127) // 128) * nt320
-        if fits and t256 >= 192:
-            v = 2
-        elif fits and t128 >= 160:
-            v = 8
-        else:
+        if not fits:
             v = 1 if N > 64 else 5
+        else:   # mirrors pick_tile (gemm.hip): rounds of 256 tiles x relative tile time
+            t256 = ((M + 255) // 256) * nt320
+            t128 = ((M + 127) // 128) * nt320
+            t1 = ((M + 127) // 128) * ((N + 127) // 128)
+            c2, c8, c1 = 10 * ((t256 + 255) // 256), 8 * ((t128 + 255) // 256), 3 * ((t1 + 255) // 256)
+            v = 2 if (c2 <= c8 and c2 <= c1) else (8 if c8 <= c1 else 1)
     tail = f"{0 if geglu else mode}, {'true' if geglu else 'false'}"
     split = {1: ", false>", 2: ", true>" if (mode != PLAIN and not geglu) else ", false>", 5: ", false>",
              6: ", false>"}.get(v, ">")   # gemm_kernel's SPLIT flag

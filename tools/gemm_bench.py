@@ -11,7 +11,7 @@ import vdx  # noqa: E402,F401
 from vdx import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-F_, B = 24, 2
+F_, B = int(os.environ.get("GEMM_BENCH_FRAMES", "24")), 2      # frames of the chunk (16 / 12: the windows of BASELINE cfg4/5)
 LEVELS = [(72, 128, 320), (36, 64, 640), (18, 32, 1280), (9, 16, 1280)]
 
 
@@ -55,11 +55,15 @@ def main():
                 ("Tin ff2 2048->512 +res", dict(mode=ops.PLAIN, cin=2048, N=512, res=True)),
                 ("Tin proj_out 512->320 +res", dict(mode=ops.PLAIN, cin=512, N=320, res=True)),
             ]
+        # the V projection of spatial self-attention, issued with swapped operands so that V arrives transposed for the
+        # flash kernel: "rows" = the C output channels, "weights" = the M activation rows
+        cases.append((f"L{lvl} v^T {C}x{M}", dict(mode=ops.PLAIN, cin=C, N=M, rows=C)))
         for name, c in cases:
             if only and only not in name:
                 continue
             taps = {ops.PLAIN: 1, ops.CONV3X3: 9, ops.TCONV3: 3}[c["mode"]]
             K = taps * c["cin"]
+            M = c.get("rows", n_img * h * w)
             a = rnd(M, c["cin"])
             wgt = rnd(c["N"], K)
             bias = rnd(c["N"])
