@@ -217,6 +217,15 @@ def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_strea
         for t_ in keep + list(got.values()):
             t_.record_stream(side)
         return got, done
+    if ref.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal of a multi-rank job whose ranks share one GPU: gloo has no device transport for send / recv, so
+        # the pieces are staged through host memory (the product's transport is RCCL, below / above)
+        host = {id(op.tensor): op.tensor.cpu() for op in p2p}
+        for r in dist.batch_isend_irecv([dist.P2POp(op.op, host[id(op.tensor)], op.peer) for op in p2p]):
+            r.wait()
+        for buf in got.values():
+            buf.copy_(host[id(buf)])
+        return got, None
     if ref.is_cuda:
         cur = torch.cuda.current_stream(ref.device)
         side = side_stream or torch.cuda.Stream(device=ref.device)
