@@ -164,7 +164,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int mt_, nt_;
     gemm_tile_of(bid, p.ntm, p.ntn, mt_, nt_);
-    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    const int m0 = p.m_begin + mt_ * BM, n0 = nt_ * BN;
     const bool does_a = !SPLIT || wave < 4, does_w = !SPLIT || wave >= 4;
 
     float2* gelu = (float2*)(smem + 2 * STAGE);    // GEGLU: table behind the stage buffers (first barrier publishes it)
@@ -260,7 +260,7 @@ static int launch(const GemmP& p, hipStream_t st) {
     if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
     GemmP q = p;
     q.ntn = (p.N + BN - 1) / BN;
-    const int ntm = (p.M + BM - 1) / BM;
+    const int ntm = (p.M - p.m_begin + BM - 1) / BM;
     q.ntm = ntm;
     hipLaunchKernelGGL(kern, dim3(ntm * q.ntn), dim3(WM * WN * 64), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16");
@@ -272,36 +272,52 @@ static int launch(const GemmP& p, hipStream_t st) {
 // 32x160 waves, 5 = 256x64, 6 = variant 2 without the
 // split staging roles (every wave issues its share of both operands at the top of the K tile); 7 (handled in
 // vdx_gemm_f16) = the weights-stationary short-K kernels of gemm_ws.hip.
+//
+// Channel widths of this UNet are multiples of 320: the 320-wide tiles (64x160 per wave) halve LDS/L2 bytes per MFMA
+// against 128x128.  Widths that are not multiples of 320 (transformer_in: 512/1536/4096) still take the 320-wide tile
+// when the masked tail wastes < 25 % of the last column of tiles.  Among the candidates a launch costs
+// (rounds of 256 tiles) x (time of one tile); tile times relative to the 256x320 tile (= 10), fitted to
+// tools/gemm_bench.py at 24 / 16 / 12 frames (profiles/r02_tools.txt): 128x320 as eight 32x160 waves 8 (half the
+// work at 62 % of the efficiency), 128x128 3 (a fifth of the work at 67 %).  The 16-frame windows of BASELINE cfg4/5
+// are where this matters: M = 18 432 rows at level 2 is 288 tiles of 256x320 = two rounds for 1.125 rounds of work,
+// and the 128x128 kernel (5.6 rounds of small tiles) is 10-16 % faster there; level 3 at 16 / 12 frames likewise.
+// K-32 rings lose to K-64 on every large shape (profiles/r01_gemm_variants.txt).
+struct TileChoice {
+    int v;            // variant
+    long long cost;   // in tenths of a 256x320 tile time
+};
+static TileChoice choose_tile(long long rows, int N) {
+    const int nt320 = (N + 319) / 320;
+    const bool fits = nt320 * 320 * 4 <= N * 5 && rows >= 1024;   // (swapped V^T products have M = C)
+    const long long t1 = ((rows + 127) / 128) * ((N + 127) / 128);
+    const long long c1 = 3 * ((t1 + 255) / 256);
+    if (!fits) return TileChoice{N > 64 ? 1 : 5, c1};
+    const long long t256 = ((rows + 255) / 256) * nt320, t128 = ((rows + 127) / 128) * nt320;
+    const long long c2 = 10 * ((t256 + 255) / 256), c8 = 8 * ((t128 + 255) / 256);
+    if (c2 <= c8 && c2 <= c1) return TileChoice{2, c2};
+    return c8 <= c1 ? TileChoice{8, c8} : TileChoice{1, c1};
+}
+// Row at which to split a product into [begin, split) on 256x320 tiles (whole rounds of 256) + [split, end) on whatever
+// suits the rest, or 0: the last round of a 256x320 launch is otherwise as slow as a full one however few tiles it has.
+static int choose_split(int begin, int end, int N) {
+    const long long rows = end - begin;
+    const TileChoice whole = choose_tile(rows, N);
+    if (whole.v != 2) return 0;
+    const int nt320 = (N + 319) / 320;
+    const long long t256 = ((rows + 255) / 256) * nt320;
+    const long long full = t256 / 256;
+    if (full == 0 || t256 % 256 == 0) return 0;
+    const long long mt_main = full * 256 / nt320;                 // m tiles of the main launch (<= `full` rounds)
+    const int split = begin + (int)(mt_main * 256);
+    if (split >= end) return 0;
+    const TileChoice tail = choose_tile(end - split, N);
+    const long long cost = 10 * ((mt_main * nt320 + 255) / 256) + tail.cost + 1;   // + 1: the second launch's ramp
+    return cost * 100 <= whole.cost * 94 ? split : 0;      // (measured in the step at 24 / 16 / 12 frames: 94 >= 100 >= 104 > 110)
+}
+
 template <int MODE, bool GEGLU>
 static int pick_tile(const GemmP& p, int force, hipStream_t st) {
-    int v = force;
-    if (v == 0) {
-        // Channel widths of this UNet are multiples of 320: the 320-wide tiles (64x160 per wave)
-        // halve LDS/L2 bytes per MFMA against 128x128.  Measured per shape (tools/gemm_bench.py,
-        // profiles/r01_gemm_variants.txt): the 256x320 two-stage K-64 kernel wins whenever its grid
-        // fills the chip; for the small-M level-3 shapes the 128x320 tile (twice the blocks) wins, as
-        // eight 32x160 waves on a four-stage ring (variant 8: 5-8 % over the four-wave two-stage variant 4,
-        // profiles/r02_tools.txt); K-32 rings lose to K-64 on every large shape.
-        // Widths that are not multiples of 320 (transformer_in: 512/1536/4096) still take the 320-wide
-        // tile when the masked tail wastes < 25 % of the last column of tiles.
-        const int nt320 = (p.N + 319) / 320;
-        const bool fits = nt320 * 320 * 4 <= p.N * 5 && p.M >= 1024;   // (swapped V^T products have M = C)
-        if (!fits) {
-            v = p.N > 64 ? 1 : 5;
-        } else {
-            // One block per CU for all three candidates, so a launch costs (rounds of 256 tiles) x (time of one tile).
-            // Tile times relative to the 256x320 tile, fitted to tools/gemm_bench.py at 24 / 16 / 12 frames
-            // (profiles/r02_tools.txt): 128x320 as eight 32x160 waves 0.8 (half the work at 62 % of the efficiency),
-            // 128x128 0.3 (a fifth of the work at 67 %).  The 16-frame windows of BASELINE cfg4/5 are where this
-            // matters: M = 18 432 rows at level 2 is 288 tiles of 256x320 = two rounds for 1.125 rounds of work, and
-            // the 128x128 kernel (5.6 rounds of small tiles) is 10-16 % faster there; level 3 at 16 / 12 frames likewise.
-            const long long t256 = (long long)((p.M + 255) / 256) * nt320;
-            const long long t128 = (long long)((p.M + 127) / 128) * nt320;
-            const long long t1 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-            const long long c2 = 10 * ((t256 + 255) / 256), c8 = 8 * ((t128 + 255) / 256), c1 = 3 * ((t1 + 255) / 256);
-            v = (c2 <= c8 && c2 <= c1) ? 2 : (c8 <= c1 ? 8 : 1);
-        }
-    }
+    const int v = force ? force : choose_tile(p.M - p.m_begin, p.N).v;
     switch (v) {
         case 1: return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
         case 2: return launch<256, 320, 4, 2, MODE, GEGLU, MODE != 0>(p, st);   // split roles pay on the gathers only
@@ -314,7 +330,8 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
     return vdx_fail("gemm: unknown kernel variant %d", v);
 }
 
-extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
+// validation + the kernel-side parameter block, shared by the launch and by vdx_gemm_plan
+static int gemm_prepare(const vdx_gemm_args* a, GemmP& p, bool& geglu, int& force, int& ws_family) {
     VDX_CHECK(a && a->a && a->w && a->out, "gemm: null pointer");
     VDX_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     VDX_CHECK(a->N % 64 == 0 && a->K % 64 == 0, "gemm: N=%d and K=%d must be multiples of 64", a->N, a->K);
@@ -326,11 +343,13 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
                   (a->residual == nullptr || a->ldr % 8 == 0),
               "gemm: leading dimensions must be multiples of 8 elements");
     VDX_CHECK(a->lda >= a->c1, "gemm: lda < c1");
-    GemmP p;
     p.a = (const f16*)a->a; p.a2 = (const f16*)a->a2; p.w = (const f16*)a->w;
     p.bias = (const f16*)a->bias; p.bias2 = (const f16*)a->bias2; p.res = (const f16*)a->residual;
     p.out = (f16*)a->out;
-    p.M = a->M; p.N = a->N; p.K = a->K; p.c1 = a->c1; p.c2 = a->c2;
+    VDX_CHECK(a->row_begin >= 0 && (a->row_end == 0 || (a->row_end > a->row_begin && a->row_end <= a->M)) && a->row_begin < a->M,
+              "gemm: rows [%d, %d) of %d", a->row_begin, a->row_end, a->M);
+    // (kernels mask rows >= p.M: the end of the row range; geometry checks below use the whole product's a->M)
+    p.M = a->row_end ? a->row_end : a->M; p.m_begin = a->row_begin; p.N = a->N; p.K = a->K; p.c1 = a->c1; p.c2 = a->c2;
     p.lda = a->lda; p.lda2 = a->lda2; p.ldo = a->ldo; p.ldr = a->ldr;
     p.h_in = a->h_in; p.w_in = a->w_in; p.h_out = a->h_out; p.w_out = a->w_out;
     p.stride = a->stride; p.ups = a->upsample ? 1 : 0;
@@ -338,25 +357,27 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
     p.ldb2 = a->ldb2 > 0 ? a->ldb2 : a->N;
     VDX_CHECK(p.ldb2 % 8 == 0, "gemm: ldb2 must be a multiple of 8");
     p.ntn = 0; p.ntm = 0;
-    hipStream_t st = (hipStream_t)stream;
-    const bool geglu = (a->epilogue & VDX_EPI_GEGLU) != 0;
-    const int force = (a->epilogue >> 8) & 15;   // kernel variant override (0 = automatic)
+    geglu = (a->epilogue & VDX_EPI_GEGLU) != 0;
+    force = (a->epilogue >> 8) & 15;   // kernel variant override (0 = automatic)
     if (geglu) {
         VDX_CHECK(a->mode == VDX_GEMM_PLAIN && !a->bias2 && !a->residual, "gemm: GEGLU epilogue is plain-mode only");
         VDX_CHECK(a->ldo % 4 == 0, "gemm: GEGLU ldo must be a multiple of 4");
     }
     // short-K Linear layers on many rows (levels 0/1, transformer_in): weights-stationary streaming kernels
-    // (variant 7 pins them)
-    if (force == 7 || (force == 0 && a->M >= 16384)) {
-        const int family = vdx_gemm_ws_family(p, a->mode, geglu);
-        if (family) return vdx_gemm_ws_launch(p, family, geglu, st);
-        VDX_CHECK(force != 7, "gemm: variant 7 (weights-stationary) needs plain single-source rows, K in {320, 512, 640}, N %% 32 == 0, M %% 64 == 0");
+    // (variant 7 pins them); they walk whole products only
+    const bool whole = a->row_begin == 0 && (a->row_end == 0 || a->row_end == a->M);
+    ws_family = 0;
+    if (whole && (force == 7 || (force == 0 && a->M >= 16384))) {
+        ws_family = vdx_gemm_ws_family(p, a->mode, geglu);
+        VDX_CHECK(ws_family || force != 7, "gemm: variant 7 (weights-stationary) needs plain single-source rows, K in {320, 512, 640}, N %% 32 == 0, M %% 64 == 0");
+    } else {
+        VDX_CHECK(force != 7, "gemm: variant 7 (weights-stationary) computes whole products (row_begin / row_end unset)");
     }
-    if (geglu) return pick_tile<0, true>(p, force, st);
     switch (a->mode) {
         case VDX_GEMM_PLAIN:
-            return pick_tile<0, false>(p, force, st);
+            break;
         case VDX_GEMM_CONV3X3:
+            VDX_CHECK(!geglu, "gemm: GEGLU epilogue is plain-mode only");
             VDX_CHECK(a->c2 == 0, "gemm: conv3x3 takes one source");
             VDX_CHECK(a->stride == 1 || a->stride == 2, "gemm: stride %d", a->stride);
             VDX_CHECK(a->h_in > 0 && a->w_in > 0 && a->h_out > 0 && a->w_out > 0, "gemm: conv geometry");
@@ -366,11 +387,45 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
                 VDX_CHECK(a->h_out == (he + 2 - 3) / a->stride + 1 && a->w_out == (we + 2 - 3) / a->stride + 1,
                           "gemm: conv output %dx%d inconsistent with input %dx%d stride %d", a->h_out, a->w_out, he, we, a->stride);
             }
-            return pick_tile<1, false>(p, force, st);
+            break;
         case VDX_GEMM_TCONV3:
+            VDX_CHECK(!geglu, "gemm: GEGLU epilogue is plain-mode only");
             VDX_CHECK(a->c2 == 0, "gemm: tconv3 takes one source");
             VDX_CHECK(a->frames > 0 && a->hw > 0 && a->M % (a->frames * a->hw) == 0, "gemm: tconv geometry M=%d F=%d HW=%d", a->M, a->frames, a->hw);
-            return pick_tile<2, false>(p, force, st);
+            break;
+        default:
+            return vdx_fail("gemm: unknown mode %d", a->mode);
     }
-    return vdx_fail("gemm: unknown mode %d", a->mode);
+    return 0;
+}
+
+extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
+    GemmP p;
+    bool geglu;
+    int force, ws_family;
+    if (const int rc = gemm_prepare(a, p, geglu, force, ws_family)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ws_family) return vdx_gemm_ws_launch(p, ws_family, geglu, st);
+    if (geglu) return pick_tile<0, true>(p, force, st);
+    switch (a->mode) {
+        case VDX_GEMM_PLAIN: return pick_tile<0, false>(p, force, st);
+        case VDX_GEMM_CONV3X3: return pick_tile<1, false>(p, force, st);
+        default: return pick_tile<2, false>(p, force, st);
+    }
+}
+
+extern "C" int vdx_gemm_plan(const vdx_gemm_args* a, int32_t* variant, int32_t* split_row) {
+    VDX_CHECK(variant && split_row, "gemm_plan: null pointer");
+    GemmP p;
+    bool geglu;
+    int force, ws_family;
+    if (const int rc = gemm_prepare(a, p, geglu, force, ws_family)) return rc;
+    *split_row = 0;
+    if (ws_family) {
+        *variant = 7;
+        return 0;
+    }
+    *variant = force ? force : choose_tile(p.M - p.m_begin, p.N).v;
+    if (!force) *split_row = choose_split(p.m_begin, p.M, p.N);
+    return 0;
 }

@@ -10,6 +10,7 @@ struct GemmP {
     int h_in, w_in, h_out, w_out, stride, ups;
     int frames, hw, rpb2, ldb2;
     int ntn, ntm;
+    int m_begin;      // first row computed (tiles start here)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

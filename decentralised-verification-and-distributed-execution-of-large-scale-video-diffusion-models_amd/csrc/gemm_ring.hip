@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int mt_, nt_;
     gemm_tile_of(bid, p.ntm, p.ntn, mt_, nt_);
-    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    const int m0 = p.m_begin + mt_ * BM, n0 = nt_ * BN;
     float2* gelu = (float2*)(smem + NS * STAGE);   // GEGLU: table behind the ring (the stage barriers publish it)
     if (GEGLU) gelu_tab_init(gelu, tid, NW * 64);
 
@@ -208,7 +208,7 @@ int launch_ring(const GemmP& p, hipStream_t st) {
     if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
     GemmP q = p;
     q.ntn = (p.N + BN - 1) / BN;
-    const int ntm = (p.M + BM - 1) / BM;
+    const int ntm = (p.M - p.m_begin + BM - 1) / BM;
     q.ntm = ntm;
     hipLaunchKernelGGL(kern, dim3(ntm * q.ntn), dim3(WMB * 128), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16");

@@ -49,7 +49,7 @@ def round_up(x: int, m: int) -> int:
 
 # --------------------------------------------------------------------------------------------
 def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=0, residual=None,
-         out=None, geglu=False, conv=None, tconv=None, variant=0):
+         out=None, geglu=False, conv=None, tconv=None, variant=0, row_begin=0, row_end=0):
     """out[M][N] = epi(gather(a|a2)[M][K] @ w[N][K]^T).  See include/vdx.h `vdx_gemm_args`."""
     lib = _lib.load()
     ar, c1, lda = _rows(a, "a")
@@ -104,17 +104,28 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     g.M, g.N, g.K, g.mode, g.c1, g.c2 = M, N, K, mode, c1, c2
     g.lda, g.ldo = lda, ldo
     g.epilogue = (EPI_GEGLU if geglu else 0) | ((variant & 15) << 8)   # variant: kernel override (tests/tuning)
-    if PROFILE is None:
+    # One product, up to two launches: whole rounds of 256 big tiles, then the rest on whatever tile suits it
+    # (vdx_gemm_plan; the bits do not depend on the split).  A pinned variant or an explicit row range is left alone.
+    spans = [(row_begin, row_end)]
+    if variant == 0 and row_begin == 0 and row_end == 0:
+        v_, split_ = C.c_int32(0), C.c_int32(0)
+        _lib.check(lib.vdx_gemm_plan(C.byref(g), C.byref(v_), C.byref(split_)), "vdx_gemm_plan")
+        if split_.value:
+            spans = [(0, split_.value), (split_.value, 0)]
+    for rb, re_ in spans:
+        g.row_begin, g.row_end = rb, re_
+        if PROFILE is None:
+            _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
+            continue
+        # bench.py instrumentation: HIP events on the launch stream around this one kernel
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
-        return out
-    # bench.py instrumentation: HIP events on the launch stream around this one kernel
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
-    ev1.record()
-    name = gemm_kernel_name(M, N, K, mode, geglu, variant, single_source=a2 is None and bias2 is None,
-                            residual=residual is not None)
-    PROFILE.append((name, 2.0 * M * N * K, ev0, ev1, (M, N, K)))
+        ev1.record()
+        rows = (re_ or M) - rb
+        name = gemm_kernel_name(rows, N, K, mode, geglu, variant, single_source=a2 is None and bias2 is None,
+                                residual=residual is not None, whole=(rb == 0 and re_ in (0, M)))
+        PROFILE.append((name, 2.0 * rows * N * K, ev0, ev1, (rows, N, K)))
     return out
 
 
@@ -125,10 +136,11 @@ WS_MIN_ROWS = 16384   # gemm.hip: smallest M the weights-stationary K=320 kernel
 
 
 def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: int = 0, single_source: bool = True,
-                     residual: bool = False) -> str:
-    """Name of the instantiation vdx_gemm_f16 launches (as rocprofv3 prints it)."""
+                     residual: bool = False, whole: bool = True) -> str:
+    """Name of the instantiation vdx_gemm_f16 launches (as rocprofv3 prints it) for M rows (`whole`: the call covers
+    the whole product — the weights-stationary kernels take no row ranges)."""
     v = variant
-    if single_source and mode == PLAIN and N % 32 == 0 and (v == 7 or (v == 0 and M >= WS_MIN_ROWS)):
+    if whole and single_source and mode == PLAIN and N % 32 == 0 and (v == 7 or (v == 0 and M >= WS_MIN_ROWS)):
         fam = None   # mirrors vdx_gemm_ws_family (gemm_ws.hip): (K, waves, chunk rows, pipelined)
         if K == 320 and M % 64 == 0:
             fam = (320, 10, 64, False) if (N % 320 == 0 and not (geglu and N % 256 == 0)) else (320, 8, 64, True)

@@ -63,9 +63,19 @@ typedef struct vdx_gemm_args {
     int32_t frames, hw;   /* tconv3: M = b*frames*hw, taps step `hw` rows, zero pad in time      */
     int32_t rows_per_bias2, ldb2; /* bias2 row = m / rows_per_bias2, row stride ldb2 elements        */
     int32_t epilogue;     /* VDX_EPI_* flags                                                     */
+    int32_t row_begin, row_end; /* only output rows [row_begin, row_end) are computed (row_end 0 = M); every pointer
+                             still addresses row 0 and M stays the whole product's row count.  Lets a caller cover one
+                             product with two calls that use different tile shapes (vdx_gemm_plan); the results are
+                             bit-identical however the rows are split                                 */
 } vdx_gemm_args;
 
 int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream);
+
+/* What vdx_gemm_f16 would do with `a` (host-only, launches nothing): *variant = the kernel family it picks for rows
+ * [row_begin, row_end) (1 = 128x128, 2 = 256x320, 8 = 128x320 ring, 5 = 256x64, 7 = weights-stationary), *split_row = a row at
+ * which splitting the product into two calls ([row_begin, split_row) and [split_row, row_end)) is expected to be faster
+ * (whole rounds of 256 big tiles + a tail of small ones instead of a mostly idle last round), or 0.                  */
+int vdx_gemm_plan(const vdx_gemm_args* a, int32_t* variant, int32_t* split_row);
 
 /* conv_in gather: (B,Cin,F,H,W) fp16 latent -> im2col rows [B*F*H*W][Kpad], K = (ky*3+kx)*Cin + ci,
  * zero padded to Kpad (multiple of 64); conv_in = this + vdx_gemm_f16 with w [Cout][Kpad]

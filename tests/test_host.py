@@ -182,3 +182,34 @@ def test_state_dict_spec_matches_oracle_module_tree():
     assert set(sd) == set(want) and all(v.dtype == torch.float16 for v in sd.values())
     assert abs(float(sd["conv_norm_out.weight"].float().mean()) - 1.0) < 0.05
     assert abs(float(sd["mid_block.temp_convs.0.conv2.0.weight"].float().mean()) - 1.0) < 0.05
+
+
+def test_gemm_plan_is_host_only_and_splits_the_mostly_idle_last_round():
+    """vdx_gemm_plan launches nothing (runs here without a GPU): the kernel family per shape and the row at which a
+    product is cut into whole rounds of 256 big tiles + a tail (level-1 width-640 shapes at 24 and 16 frames)."""
+    import ctypes as C
+    from vdx import _lib
+    lib = _lib.load()
+
+    def plan(M, N, K, mode=0, taps=1, **kw):
+        g = _lib.GemmArgs()
+        g.a = g.w = g.out = 1 << 20            # never dereferenced on the host
+        g.M, g.N, g.K, g.mode, g.c1 = M, N, K, mode, K // taps
+        g.lda, g.ldo = K // taps, N
+        for k, v in kw.items():
+            setattr(g, k, v)
+        v, s = C.c_int32(-1), C.c_int32(-1)
+        assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) == 0, lib.vdx_last_error()
+        return v.value, s.value
+
+    assert plan(110592, 640, 1920, mode=2, taps=3, frames=24, hw=2304) == (2, 98304)     # 3.375 rounds -> 3 + tail
+    assert plan(73728, 640, 1920, mode=2, taps=3, frames=16, hw=2304) == (2, 65536)       # 2.25 rounds -> 2 + tail
+    assert plan(73728, 640, 1920, mode=2, taps=3, frames=16, hw=2304, row_begin=65536) == (1, 0)   # the tail: 128x128
+    assert plan(442368, 320, 960, mode=2, taps=3, frames=24, hw=9216) == (2, 0)           # 6.75 rounds: not worth it
+    assert plan(18432, 1280, 1280) == (1, 0)                                              # 16-frame level 2
+    assert plan(6912, 1280, 1280) == (8, 0)                                               # level 3
+    assert plan(442368, 320, 320) == (7, 0)                                               # weights-stationary
+    assert plan(442368, 320, 320, row_end=1024)[0] != 7                                   # ... whole products only
+    g = _lib.GemmArgs()
+    v, s = C.c_int32(), C.c_int32()
+    assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) != 0 and b"null" in lib.vdx_last_error()

@@ -100,6 +100,57 @@ def test_gemm_320_wide_kernels_all_modes(gpu, variant):
     close(ops.gemm(d(rows), d(packing.pack_tconv3(w)), M=B * Fr * HW, mode=ops.TCONV3, tconv=(Fr, HW), variant=variant), ref)
 
 
+@pytest.mark.parametrize("split,v_head,v_tail", [(4096, 2, 1), (5000, 2, 8), (256, 1, 2), (12288, 8, 3)])
+def test_gemm_row_ranges_are_bit_identical_to_the_whole_product(gpu, split, v_head, v_tail):
+    """vdx_gemm_args.row_begin / row_end: one product covered by two calls on different tile shapes (any split row,
+    not only tile multiples) carries the bits of the single call, in every gather mode."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(split)
+    d = lambda t: t.half().to(gpu)
+
+    def both(**kw):
+        whole = ops.gemm(variant=2, **kw)
+        out = torch.full_like(whole, float("nan"))
+        ops.gemm(variant=v_head, row_end=split, out=out, **kw)
+        assert torch.isnan(out[split:].float()).all()              # rows past row_end untouched
+        ops.gemm(variant=v_tail, row_begin=split, out=out, **kw)
+        assert torch.equal(out, whole)
+
+    M, c1, c2, N = 12300 + 77, 64, 128, 640
+    both(a=d(torch.randn(M, c1, generator=g)), w=d(torch.randn(N, c1 + c2, generator=g) / 13), M=M,
+         a2=d(torch.randn(M, c2, generator=g)), bias=d(torch.randn(N, generator=g)), residual=d(torch.randn(M, N, generator=g)))
+    n, hh, ww, cin, cout = 3, 65, 64, 128, 320                       # 12480 rows; temb row per image
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    wc = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    both(a=d(packing.nchw_to_rows(x)), w=d(packing.pack_conv3x3(wc)), M=n * hh * ww, mode=ops.CONV3X3,
+         bias2=d(torch.randn(n, cout, generator=g)), rows_per_bias2=hh * ww, conv=(n, hh, ww, hh, ww, 1, False))
+    B, Fr, HW, C, Co = 2, 6, 1031, 64, 640                           # 12372 rows
+    rows = h(torch.randn(B * Fr * HW, C, generator=g))
+    wt = h(torch.randn(Co, C, 3, 1, 1, generator=g) / 14)
+    both(a=d(rows), w=d(packing.pack_tconv3(wt)), M=B * Fr * HW, mode=ops.TCONV3, tconv=(Fr, HW),
+         bias=d(torch.randn(Co, generator=g)))
+
+
+def test_gemm_automatic_tail_split(gpu):
+    """A 16-frame level-1 temporal conv (73 728 x 640, 2.25 rounds of 256x320 tiles): the automatic path runs two whole
+    rounds + a 128x128 tail (vdx_gemm_plan) and returns the bits of the single 256x320 launch; bench.py's per-launch
+    records name both kernels."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, Fr, HW, C = 2, 16, 2304, 640
+    M = B * Fr * HW
+    rows = torch.randn(M, C, generator=g).half().to(gpu)
+    w = packing.pack_tconv3(h(torch.randn(C, C, 3, 1, 1, generator=g) / 40)).half().to(gpu)
+    one = ops.gemm(rows, w, M=M, mode=ops.TCONV3, tconv=(Fr, HW), variant=2)
+    ops.PROFILE = rec = []
+    try:
+        auto = ops.gemm(rows, w, M=M, mode=ops.TCONV3, tconv=(Fr, HW))
+    finally:
+        ops.PROFILE = None
+    assert torch.equal(auto, one)
+    assert [(r[0].split("<")[1][:8], r[4][0]) for r in rec] == [("256, 320", 65536), ("128, 128", 8192)]
+
+
 @pytest.mark.parametrize("M,N,K,flags", [
     (64, 320, 320, "bias"), (192, 640, 320, "none"), (4160, 960, 320, "bias"), (1984, 320, 320, "bias+res"),
     (16448, 320, 320, "bias+res"), (704, 1600, 320, "geglu"), (20480, 1920, 320, "none"),      # 10 waves, 320-wide panels

@@ -74,7 +74,7 @@ def main():
             byts = 2.0 * (M * c["cin"] + M * n_out + (M * c["N"] if res is not None else 0) + c["N"] * K)
             per = []
             ws_ok = c["mode"] == ops.PLAIN and K in (320, 512, 640)
-            for v in (1, 2, 3, 4, 7, 8):
+            for v in (1, 2, 3, 4, 7, 8, 0):
                 if v == 7 and not ws_ok:
                     per.append(float("inf"))
                     continue
@@ -87,7 +87,7 @@ def main():
             auto = ops.gemm_kernel_name(M, c["N"], K, c["mode"], c.get("geglu", False))
             rows.append((name, M, c["N"], K, per, flops, byts, auto))
             del a, wgt, out, res
-    names = ["128x128", "256x320", "ring4", "128x320", "ws", "128x320w8"]
+    names = ["128x128", "256x320", "ring4", "128x320", "ws", "128x320w8", "auto"]
     print(f"{'shape':30s} {'M':>7s} {'N':>6s} {'K':>6s} | ms: " + " ".join(f"{n:>8s}" for n in names) +
           " | best TF/s  GB/s | auto")
     for r in rows:
