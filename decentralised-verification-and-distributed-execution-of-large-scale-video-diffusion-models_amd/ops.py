@@ -328,9 +328,18 @@ def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, o
     orow, ocol, ldo = _rows(out, "out")
     if orow < n_seq * sq or ocol < inner:
         raise VdxError("flash_attn: out too small")
+    if PROFILE is not None:        # bench.py instrumentation (as in gemm): HIP events on the launch stream
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(lib.vdx_flash_attn_f16(_p(q, "q"), ldq, _p(k, "k"), ldk, _p(vt, "vt"), ldvt, _p(out, "out"), ldo,
                                       n_seq, sq, skv, skv_pad, heads, seq_per_kv, float(scale), int(bool(causal)), _stream()),
                "vdx_flash_attn_f16")
+    if PROFILE is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        two = sq >= 512 and skv >= 256                      # flash.hip: 64 queries per wave
+        name = f"flash_attn_kernel<{2 if two else 1}, {'true' if causal else 'false'}>"
+        PROFILE.append((name, 4.0 * n_seq * heads * sq * skv * 64, ev0, ev1, (n_seq * sq, skv, heads * 64)))
     return out
 
 
