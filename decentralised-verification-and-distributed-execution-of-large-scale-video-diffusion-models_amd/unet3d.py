@@ -307,18 +307,27 @@ class UNet3DConditionModel(nn.Module):
             sc = x
         geo = (n_img, hh, ww, hh, ww, 1, False)
         B = n_img // F
-        if self.ff_block_bytes and x2 is not None and n_img % 2 == 0 and (B == 1 or B % 2 == 0) and M * cout * 2 > (64 << 20):
-            # memory-lean mode, concat input (up path): the normalised concat [rows][2C] is the widest tensor of the
-            # block; GroupNorm (4-D: statistics per image) -> conv1 runs over the images in two halves, so only half
-            # of it exists at a time.  Same kernels per image, same bits.
+        pieces = 0
+        if self.ff_block_bytes and x2 is not None and M * cout * 2 > (64 << 20):
+            # memory-lean mode, concat input (up path): the normalised concat [rows][C1 + C2] is the widest tensor of
+            # the block; GroupNorm (4-D: statistics per image) -> conv1 runs over the images in pieces of whole frames
+            # of ONE batch item (the time-embedding row of a piece is then row 0 of `temb_all[b:]`), sized to about
+            # at most 160 MB (8 frames of the 960-channel level-0 concat: pieces of 73 728 rows still fill the chip),
+            # so only a piece of it exists at a time.  Same kernels per image, same bits.
+            cin = x.shape[1] + x2.shape[1]
+            per_item = next((k for k in range(1, F + 1) if F % k == 0 and (F // k) * S * cin * 2 <= (160 << 20)), F)
+            pieces = B * per_item
+        if pieces > 1:
             h = torch.empty((M, cout), dtype=torch.float16, device=x.device)
-            hm, hn = M // 2, n_img // 2
-            for r0 in (0, hm):
-                n1 = ops.groupnorm(x[r0:r0 + hm], W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=hn,
-                                   rows_per_sample=S, eps=eps, silu_act=True, x2=x2[r0:r0 + hm], partition_samples=n_img)
-                ops.gemm(n1, W[p + ".conv1.weight"], M=hm, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
+            pn = n_img // pieces                    # images (frames) per piece
+            pm = pn * S
+            for i in range(pieces):
+                r0 = i * pm
+                n1 = ops.groupnorm(x[r0:r0 + pm], W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=pn,
+                                   rows_per_sample=S, eps=eps, silu_act=True, x2=x2[r0:r0 + pm], partition_samples=n_img)
+                ops.gemm(n1, W[p + ".conv1.weight"], M=pm, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
                          bias2=temb_all[r0 // (F * S):, off:off + cout], rows_per_bias2=F * S,
-                         conv=(hn, hh, ww, hh, ww, 1, False), out=h[r0:r0 + hm])
+                         conv=(pn, hh, ww, hh, ww, 1, False), out=h[r0:r0 + pm])
                 del n1
             del x, x2
         else:
