@@ -213,3 +213,10 @@ def test_gemm_plan_is_host_only_and_splits_the_mostly_idle_last_round():
     g = _lib.GemmArgs()
     v, s = C.c_int32(), C.c_int32()
     assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) != 0 and b"null" in lib.vdx_last_error()
+    for bad in (dict(row_begin=4096), dict(row_begin=100, row_end=50), dict(row_end=5000), dict(row_begin=-1)):
+        g = _lib.GemmArgs()
+        g.a = g.w = g.out = 1 << 20
+        g.M, g.N, g.K, g.c1, g.lda, g.ldo = 4096, 320, 1280, 1280, 1280, 320
+        for k, val in bad.items():
+            setattr(g, k, val)
+        assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) != 0 and b"rows [" in lib.vdx_last_error(), bad
