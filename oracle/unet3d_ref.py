@@ -59,7 +59,7 @@ class UNet3DConfig:
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     """diffusers `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)`."""
     half = dim // 2
-    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     a = t.float()[:, None] * freqs[None]
     return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
 
