@@ -364,7 +364,11 @@ class UNet3DConditionModel(nn.Module):
             # GEGLU intermediate [rows][4*inner] is the largest tensor of the forward (1.2 GB at 16 frames in
             # transformer_in); rows are independent, so the feed-forward runs over row blocks and only one block's
             # intermediate is alive at a time.  Same kernels, same bits.
-            blk = max(16384, (self.ff_block_bytes // (8 * inner)) // 4096 * 4096)
+            # (only where it matters for the peak: intermediates above 256 MB, i.e. levels 0 / 1 and transformer_in; the
+            # blocks are made even — 18 432 rows used to be cut into 16 384 + 2 048)
+            if M * 8 * inner > (256 << 20):
+                nblk = -(-M * 8 * inner // self.ff_block_bytes)
+                blk = max(16384, ((M + nblk - 1) // nblk + 4095) // 4096 * 4096)
         if blk >= M:
             ln = ops.layernorm(t, W[b + ".norm3.weight"], W[b + ".norm3.bias"], M=M)
             gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=M, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
@@ -398,7 +402,7 @@ class UNet3DConditionModel(nn.Module):
         if Mp != M:
             ln[M:].zero_()
         ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
-        if S % 8 == 0 and self.ff_block_bytes and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (64 << 20):
+        if S % 8 == 0 and self.ff_block_bytes and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (128 << 20):
             # memory-lean mode: images are independent in the self-attention, so q|k, V^T and the attention run over
             # the images in two halves and only half of those intermediates ([rows][2C] + [C][rows]) is alive at a time
             o = torch.empty((M, C), dtype=torch.float16, device=x.device)
