@@ -108,10 +108,14 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     # (vdx_gemm_plan; the bits do not depend on the split).  A pinned variant or an explicit row range is left alone.
     spans = [(row_begin, row_end)]
     if variant == 0 and row_begin == 0 and row_end == 0:
-        v_, split_ = C.c_int32(0), C.c_int32(0)
-        _lib.check(lib.vdx_gemm_plan(C.byref(g), C.byref(v_), C.byref(split_)), "vdx_gemm_plan")
-        if split_.value:
-            spans = [(0, split_.value), (split_.value, 0)]
+        key = (M, N, K, mode, geglu, a2 is not None, bias2 is not None)      # everything the plan depends on
+        split = _PLAN_CACHE.get(key)
+        if split is None:
+            v_, split_ = C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.vdx_gemm_plan(C.byref(g), C.byref(v_), C.byref(split_)), "vdx_gemm_plan")
+            split = _PLAN_CACHE[key] = split_.value
+        if split:
+            spans = [(0, split), (split, 0)]
     for rb, re_ in spans:
         g.row_begin, g.row_end = rb, re_
         if PROFILE is None:
@@ -129,6 +133,7 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     return out
 
 
+_PLAN_CACHE = {}
 PROFILE = None   # set to a list by bench.py to collect (kernel name, algorithmic FLOPs, start, end)
 
 
