@@ -119,6 +119,10 @@ def main():
                     help="rehearsal aid: gloo lets several ranks of a real multi-process job share ONE GPU (with --share-gpu); "
                          "the driver's runs use nccl (= RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal aid: every rank computes on cuda:0")
+    ap.add_argument("--peaked", action="store_true",
+                    help="diagnostic: scale the spatial self-attention q|k projections x2 each (scores x4: row maxima tens of "
+                         "nats above the mean, as trained checkpoints have) — the lazy softmax offset of the flash kernel then "
+                         "has to move; the default synthetic weights give near-uniform attention, its best case")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--ff-block-mb", type=int, default=0, help="diagnostic: feed-forward row-block size of the memory-lean mode")
     ap.add_argument("--resident", action="store_true",
@@ -163,6 +167,10 @@ def main():
     H, W = 72, 128
     cfg = UNet3DConfig.zeroscope()
     unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
+    if args.peaked:
+        for k_, w_ in unet.W.items():
+            if k_.endswith(".attn1.to_qk.weight"):
+                w_.mul_(2.0)
     if dist_mode and not args.resident:
         unet.shard_(rank, world)       # 1/N of every unit per GPU, per-unit RCCL all-gather
     if args.ff_block_mb:
