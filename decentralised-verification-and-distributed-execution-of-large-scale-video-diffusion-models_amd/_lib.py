@@ -53,6 +53,9 @@ SIGNATURES = {
     "vdx_temporal_attn_block_wqkv_bytes": (_sz, [_i]),
     "vdx_temporal_attn_block_wo_bytes": (_sz, [_i]),
     "vdx_temporal_attn_block_f16": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "vdx_temporal_attn_block2_supported": (_i, [_i, _i]),
+    "vdx_temporal_attn_block2_pack_bytes": (_sz, [_i]),
+    "vdx_temporal_attn_block2_f16": (_i, [_vp, _i, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "vdx_comm_unique_id": (_i, [_vp]),
     "vdx_comm_init": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "vdx_comm_destroy": (_i, [_vp]),

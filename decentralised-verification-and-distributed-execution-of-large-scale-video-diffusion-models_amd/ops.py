@@ -365,6 +365,35 @@ def temporal_attn(qkv, *, B, F, HW, heads, scale, out=None):
     return out
 
 
+def temporal_attn_block2_supported(inner: int, F: int) -> bool:
+    return bool(_lib.load().vdx_temporal_attn_block2_supported(inner, F))
+
+
+def temporal_attn_block2(t, packed, *, B, F, HW, eps=1e-5, out=None):
+    """K7, second design (csrc/tattn2.hip): t + to_out(attention_over_frames(LayerNorm(t))) in one kernel; LayerNorm's
+    affine, the softmax scale and the biases are inside `packed` (packing.pack_k7b)."""
+    lib = _lib.load()
+    r, inner, ldt = _rows(t, "t")
+    M = B * F * HW
+    if r < M:
+        raise VdxError(f"temporal_attn_block2: t has {r} rows, need {M}")
+    if not lib.vdx_temporal_attn_block2_supported(inner, F):
+        raise VdxError(f"temporal_attn_block2: inner={inner}, F={F} not supported by the fused kernel")
+    if packed.dtype != torch.float16 or packed.numel() * 2 != lib.vdx_temporal_attn_block2_pack_bytes(inner) \
+            or not packed.is_contiguous():
+        raise VdxError("temporal_attn_block2: packed blob does not match the kernel's layout (packing.pack_k7b)")
+    if out is None:
+        out = torch.empty((M, inner), dtype=torch.float16, device=t.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < inner:
+        raise VdxError("temporal_attn_block2: out too small")
+    if out.data_ptr() == t.data_ptr():
+        raise VdxError("temporal_attn_block2: out may not alias t")
+    _lib.check(lib.vdx_temporal_attn_block2_f16(_p(t, "t"), ldt, _p(packed, "packed"), float(eps), _p(out, "out"), ldo,
+                                                B, F, HW, inner, _stream()), "vdx_temporal_attn_block2_f16")
+    return out
+
+
 def temporal_attn_block_supported(inner: int, F: int) -> bool:
     return bool(_lib.load().vdx_temporal_attn_block_supported(inner, F))
 

@@ -138,3 +138,75 @@ def pack_k7_out(wo: torch.Tensor) -> torch.Tensor:
     out = wo.new_zeros((ncg, ks, stage))
     out[:, :, :nch * cg * 512] = w.reshape(ncg, ks, -1)
     return out.reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# K7, second design (csrc/tattn2.hip): ONE packed blob per attention sub-block.
+#   [heads][15 units]  q|k|v stream: per head q0 k0 q1 k1 .. q4 k4 v0 .. v4, a unit = 64 weight rows x 64 k as 8 tiles
+#                      (tile 4*kk + j: rows 16j .. 16j+15, MFMA k step 2m + kk), tile format as above;
+#   [2 full column groups][heads][2 units] + [last 64 columns][heads][1 unit]  output projection, contracted head by
+#                      head; its k index is PERMUTED so that the P.V accumulators of the kernel are its B operand
+#                      as they stand: element j8 of lane quad q4 of k step (h, kk) is channel
+#                      64h + 32kk + 16*(j8 >> 2) + 4*q4 + (j8 & 3);
+#   fp32 [inner] q bias, fp32 [inner] output bias.
+# LayerNorm's affine and the softmax scale are folded in here: W_q' = c.W_q.diag(gamma) (c = scale.log2 e),
+# W_k' = W_k.diag(gamma), W_v' = W_v.diag(gamma); q bias = c.W_q.beta; the k bias adds a per-query constant to the
+# scores (softmax-invariant) and is dropped; the v bias passes through the softmax (rows of P sum to 1) into the
+# output bias: b_o' = b_o + W_o.(W_v.beta).
+# ---------------------------------------------------------------------------------------------
+K7B_WIDTHS = (320,)
+
+
+def _k7b_units(w: torch.Tensor, heads: int, km: int) -> torch.Tensor:
+    """[heads*64][inner] -> [heads][km][8 tiles][16][4][8] (tile = 4*kk + j)."""
+    x = w.reshape(heads, 4, 16, km, 2, 4, 8)              # [h][j][n][m][kk][chunk][8]
+    x = x.permute(0, 3, 4, 1, 2, 5, 6)                     # [h][m][kk][j][n][chunk][8]
+    return x.reshape(heads, km, 8, 16, 4, 8)
+
+
+def pack_k7b(wq, wk, wv, wo, gamma, beta, bo, scale: float) -> torch.Tensor:
+    """-> fp16 tensor holding the blob (the two fp32 vectors at its end are stored as raw bits)."""
+    inner = wq.shape[0]
+    assert inner in K7B_WIDTHS and inner % 128 == 64
+    heads, km = inner // 64, inner // 64
+    dev = wq.device
+    f = lambda x: x.to(device=dev, dtype=torch.float32)    # noqa: E731
+    wq, wk, wv, wo, gamma, beta, bo = (f(x) for x in (wq, wk, wv, wo, gamma, beta, bo))
+    c = float(scale) * 1.4426950408889634
+    q16 = (wq * gamma[None, :] * c).half()
+    k16 = (wk * gamma[None, :]).half()
+    v16 = (wv * gamma[None, :]).half()
+    bq = c * (wq @ beta)
+    bo2 = bo + wo @ (wv @ beta)
+    uq, uk, uv = (_k7b_units(x, heads, km) for x in (q16, k16, v16))
+    qk = torch.stack([uq, uk], dim=2).reshape(heads, 2 * km, 8, 16, 4, 8)
+    qkv = _k7_slot_swizzle(torch.cat([qk, uv], dim=1)).reshape(-1)             # [h][15][8][16][4][8]
+    # output projection
+    wo16 = wo.half()
+    ar = lambda n: torch.arange(n, device=dev)             # noqa: E731
+    chunk, j8 = ar(4)[:, None], ar(8)[None, :]
+    kperm = 16 * (j8 >> 2) + 4 * chunk + (j8 & 3)                               # [4][8] channel inside a 32-wide k step
+    n = ar(16)
+
+    def cols(base, ntile):
+        jt = ar(ntile)[:, None]
+        return base + 32 * (jt // 2) + 8 * (n[None, :] >> 2) + 4 * (jt % 2) + (n[None, :] & 3)     # [ntile][16]
+
+    parts = []
+    for cg in range(inner // 128):
+        col = cols(128 * cg, 8)                                                 # [8][16]
+        u = torch.empty((heads, 2, 8, 16, 4, 8), dtype=torch.float16, device=dev)
+        for h in range(heads):
+            for kk in range(2):
+                ch = 64 * h + 32 * kk + kperm                                   # [4][8]
+                u[h, kk] = wo16[col[:, :, None, None], ch[None, None]]
+        parts.append(_k7_slot_swizzle(u).reshape(-1))
+    col = cols(128 * (inner // 128), 4)                                         # [4][16]
+    u = torch.empty((heads, 2, 4, 16, 4, 8), dtype=torch.float16, device=dev)
+    for h in range(heads):
+        for kk in range(2):
+            ch = 64 * h + 32 * kk + kperm
+            u[h, kk] = wo16[col[:, :, None, None], ch[None, None]]
+    parts.append(_k7_slot_swizzle(u).reshape(-1))                               # [h][tile 4*kk + jt][16][4][8]
+    vec = torch.cat([bq, bo2]).contiguous().view(torch.float16)
+    return torch.cat([qkv] + parts + [vec]).contiguous()

@@ -119,7 +119,7 @@ class UNet3DConditionModel(nn.Module):
             q, k, v = (packing.pack_conv1x1(get(f"{prefix}.to_{n}.weight")) for n in "qkv")
             if fuse_v:      # temporal attention: one [3*inner][inner] projection
                 put(prefix + ".to_qkv.weight", torch.cat([q, k, v], 0))
-                if q.shape[0] in packing.K7_GEOMETRY:      # widths the fused sub-block kernel (K7) is built for
+                if q.shape[0] in packing.K7_GEOMETRY and q.shape[0] not in packing.K7B_WIDTHS:      # widths only the first fused sub-block kernel (K7) is built for
                     put(prefix + ".k7_qkv", packing.pack_k7_qkv(q, k, v))
                     put(prefix + ".k7_out", packing.pack_k7_out(packing.pack_conv1x1(get(f"{prefix}.to_out.0.weight"))))
             else:           # spatial self-attention: [q|k] fused, V issued as the swapped GEMM (-> V^T)
@@ -150,6 +150,13 @@ class UNet3DConditionModel(nn.Module):
                 attn_cross(b + ".attn2")
             ff(b + ".ff")
             lin(prefix + ".proj_out")
+            if temporal and sd[b + ".attn1.to_q.weight"].shape[0] in packing.K7B_WIDTHS:
+                # K7, second design: one blob per attention sub-block with its LayerNorm folded in (csrc/tattn2.hip)
+                for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
+                    put(f"{b}.{a}.k7b", packing.pack_k7b(
+                        *(packing.pack_conv1x1(sd[f"{b}.{a}.to_{n}.weight"]) for n in "qkv"),
+                        packing.pack_conv1x1(sd[f"{b}.{a}.to_out.0.weight"]), sd[f"{b}.{nm}.weight"], sd[f"{b}.{nm}.bias"],
+                        sd[f"{b}.{a}.to_out.0.bias"], c.attention_head_dim ** -0.5))
 
         def resnet(prefix):
             norm(prefix + ".norm1"); norm(prefix + ".norm2")
@@ -471,7 +478,11 @@ class UNet3DConditionModel(nn.Module):
         t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
         del n
         fused = self.fuse_temporal_attention and f"{b}.attn1.k7_qkv" in W and ops.temporal_attn_block_supported(t.shape[1], F)
+        fused2 = self.fuse_temporal_attention and f"{b}.attn1.k7b" in W and ops.temporal_attn_block2_supported(t.shape[1], F)
         for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
+            if fused2:     # K7, second design (inner 320)
+                t = ops.temporal_attn_block2(t, W[f"{b}.{a}.k7b"], B=B, F=F, HW=S)
+                continue
             if fused:      # K7: LayerNorm -> q|k|v -> F x F attention -> to_out + residual in one kernel
                 t = ops.temporal_attn_block(t, W[f"{b}.{nm}.weight"], W[f"{b}.{nm}.bias"], W[f"{b}.{a}.k7_qkv"],
                                             W[f"{b}.{a}.k7_out"], W[f"{b}.{a}.to_out.0.bias"], B=B, F=F, HW=S, scale=scale)

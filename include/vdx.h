@@ -164,6 +164,15 @@ int vdx_temporal_attn_block_f16(const void* t, int ldt, const void* gamma, const
                                 void* out, int ldo, int B, int F, int HW, int inner, float scale,
                                 vdx_stream_t stream);
 
+/* K7, second design (csrc/tattn2.hip) — the same sub-block (`s = s + attn(LN(s))`; call site
+ * fsdp_chunked_coherent.py:140) with LayerNorm's affine, the softmax scale and all biases folded into ONE packed blob
+ * (vdx/packing.py pack_k7b: q|k|v units, output-projection units with the permuted k index, fp32 q bias, fp32 output
+ * bias; vdx_temporal_attn_block2_pack_bytes bytes).  t / out as above.  Supported: inner 320, F a divisor of 48.   */
+int vdx_temporal_attn_block2_supported(int inner, int F);
+size_t vdx_temporal_attn_block2_pack_bytes(int inner);
+int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* packed, float eps, void* out, int ldo,
+                                 int B, int F, int HW, int inner, vdx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Orchestration ops the reference owns (fsdp_chunked_coherent.py).
  * ---------------------------------------------------------------------------------------- */

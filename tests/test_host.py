@@ -119,9 +119,10 @@ def test_unet_weight_ingest_covers_every_diffusers_key():
     m = UNet3DConditionModel(UNet3DConfig.zeroscope())
     m.load_diffusers_state_dict(sd, device="meta")
     # + conv_out rows padded 4 -> 64, conv_in K padded 36 -> 64
-    # + the K7 stage images (a second, re-laid-out copy of the temporal q|k|v / to_out weights at widths 320 and 512;
-    #   to_out padded to the q|k|v stage size): 5 level-0 temporal transformers and transformer_in, 2 attentions each
-    k7 = 10 * (3 * 320 * 320 + 2 * 10 * 6144) + 2 * (3 * 512 * 512 + 2 * 16 * 12288)
+    # + the K7 images (a second, re-laid-out copy of the temporal q|k|v / to_out weights): width 320 (5 level-0 temporal
+    #   transformers, 2 attentions each) as the blobs of csrc/tattn2.hip — 100 units of 8 KB + two fp32 vectors — and
+    #   width 512 (transformer_in) as the stage images of csrc/tattn_fused.hip (to_out padded to the q|k|v stage size)
+    k7 = 10 * (100 * 4096 + 2 * 2 * 320) + 2 * (3 * 512 * 512 + 2 * 16 * 12288)
     assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7
     assert m.config.in_channels == 4
     sd["bogus.weight"] = torch.empty(1, device="meta")
@@ -220,3 +221,30 @@ def test_gemm_plan_is_host_only_and_splits_the_mostly_idle_last_round():
         for k, val in bad.items():
             setattr(g, k, val)
         assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) != 0 and b"rows [" in lib.vdx_last_error(), bad
+
+
+@pytest.mark.parametrize("Fr,rot", [(24, 0), (16, 3), (12, 1), (8, 4), (48, 2)])
+def test_k7b_packing_matches_kernel_indexing(Fr, rot):
+    """packing.pack_k7b against a lane-level walk through csrc/tattn2.hip's own addressing (tests/k7b_emulator.py: the
+    unit / tile / slot arithmetic, the MFMA lane maps, the accumulator-as-operand hand-offs and the permuted k index of
+    the output projection), compared with the fp32 statement of the sub-block on one 48-row group."""
+    import numpy as np
+    import torch.nn.functional as Fn
+    from k7b_emulator import Wave, p0
+    from vdx import packing
+    inner, heads = 320, 5
+    G = 48 // Fr
+    g = torch.Generator().manual_seed(7 + Fr)
+    h = lambda x: x.half().float()    # noqa: E731
+    t = h(torch.randn(48, inner, generator=g) * 1.5 + 0.3)          # rows in group order: row = pixel * Fr + frame
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    wq, wk, wv, wo = (h(torch.randn(inner, inner, generator=g) * s_) for s_ in (0.09, 0.09, 0.06, 0.05))
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    ln = Fn.layer_norm(t, (inner,), gamma, beta, 1e-5)
+    seq = lambda x: x.reshape(G, Fr, heads, 64).permute(0, 2, 1, 3)   # noqa: E731
+    a = torch.softmax(seq(ln @ wq.t()) @ seq(ln @ wk.t()).transpose(-1, -2) * 0.125, -1) @ seq(ln @ wv.t())
+    ref = (t + a.permute(0, 2, 1, 3).reshape(48, inner) @ wo.t() + bo).numpy()
+    blob = packing.pack_k7b(wq, wk, wv, wo, gamma, beta, bo, 0.125)
+    assert blob.dtype == torch.float16 and blob.numel() == 100 * 4096 + 2 * 2 * inner
+    out = Wave(blob.numpy(), inner, Fr, rot).run(p0(t.numpy(), 1e-5), t.numpy())
+    assert np.abs(out - ref).max() <= 3e-3 * np.abs(ref).max() + 3e-3

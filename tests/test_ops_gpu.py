@@ -522,10 +522,68 @@ def test_temporal_attn_block_fused(gpu, inner, B, Fr, HW):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("B,Fr,HW", [(2, 24, 20), (1, 16, 7), (2, 12, 9), (1, 8, 5), (1, 24, 1), (2, 6, 33), (1, 48, 3),
+                                     (1, 1, 100), (2, 24, 301), (1, 16, 515), (2, 3, 64), (1, 2, 777)])
+def test_temporal_attn_block2_fused(gpu, B, Fr, HW):
+    """K7, second design (csrc/tattn2.hip, inner 320): LayerNorm (folded into the packed weights) -> q|k -> scores ->
+    v -> P.V -> to_out + bias + residual in one kernel, against the fp32 statement of the sub-block and
+    against the un-fused kernels.  F in {24, 16, 12} (the BASELINE chunks) and other divisors of 48; pixel counts that do
+    not fill the last row group / the last block, and counts that give many blocks (every rotation of the head order)."""
+    ops, _ = _ops()
+    from vdx import packing
+    inner, heads = 320, 5
+    g = torch.Generator().manual_seed(inner + Fr + HW)
+    M = B * Fr * HW
+    t = h(torch.randn(M, inner, generator=g) * 1.5 + 0.3)
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    wq, wk, wv, wo = (h(torch.randn(inner, inner, generator=g) * s_) for s_ in (0.09, 0.09, 0.06, 0.05))
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    ref = _temporal_block_ref(t, gamma, beta, wq, wk, wv, wo, bo, B, Fr, HW, heads)
+    d = lambda x: x.half().to(gpu)   # noqa: E731
+    assert ops.temporal_attn_block2_supported(inner, Fr)
+    blob = packing.pack_k7b(wq, wk, wv, wo, gamma, beta, bo, 0.125).to(gpu)
+    out = ops.temporal_attn_block2(d(t), blob, B=B, F=Fr, HW=HW)
+    close(out, ref, tol=4e-3)
+    ln = ops.layernorm(d(t), d(gamma), d(beta), M=M)
+    qkv = ops.gemm(ln, d(torch.cat([wq, wk, wv], 0)), M=M)
+    o = ops.temporal_attn(qkv, B=B, F=Fr, HW=HW, heads=heads, scale=0.125)
+    unf = ops.gemm(o, d(wo), M=M, bias=d(bo), residual=d(t))
+    close(out, unf.float().cpu(), tol=4e-3)
+    # a second launch gives the same bits (no dependence on block scheduling); a strided input / output too
+    out2 = ops.temporal_attn_block2(d(t), blob, B=B, F=Fr, HW=HW)
+    assert torch.equal(out, out2)
+    wide_in = torch.zeros(M, inner + 64, dtype=torch.float16, device=gpu)
+    wide_in[:, :inner] = d(t)
+    wide_out = torch.full((M, inner + 8), 7.0, dtype=torch.float16, device=gpu)
+    ops.temporal_attn_block2(wide_in[:, :inner], blob, B=B, F=Fr, HW=HW, out=wide_out[:, :inner])
+    assert torch.equal(wide_out[:, :inner], out) and bool((wide_out[:, inner:] == 7.0).all())
+
+
+def test_temporal_attn_block2_large_mean(gpu):
+    """Rows whose mean is far from zero (|mean| = 40 sigma): the statistics are two-pass fp32, the centred row is
+    formed as x * rstd - mean * rstd in fp32 before the fp16 rounding."""
+    ops, _ = _ops()
+    from vdx import packing
+    inner, heads, B, Fr, HW = 320, 5, 1, 24, 16
+    g = torch.Generator().manual_seed(5)
+    M = B * Fr * HW
+    t = h(torch.randn(M, inner, generator=g) * 0.5 + 20.0)
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    wq, wk, wv, wo = (h(torch.randn(inner, inner, generator=g) * s_) for s_ in (0.09, 0.09, 0.06, 0.05))
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    ref = _temporal_block_ref(t, gamma, beta, wq, wk, wv, wo, bo, B, Fr, HW, heads)
+    blob = packing.pack_k7b(wq, wk, wv, wo, gamma, beta, bo, 0.125).to(gpu)
+    out = ops.temporal_attn_block2(t.half().to(gpu), blob, B=B, F=Fr, HW=HW)
+    close(out, ref, tol=4e-3)
+
+
 def test_temporal_attn_block_rejects_unsupported(gpu):
     ops, _ = _ops()
     from vdx._lib import VdxError
     assert not ops.temporal_attn_block_supported(320, 5) and not ops.temporal_attn_block_supported(640, 24)
+    assert not ops.temporal_attn_block2_supported(512, 24) and not ops.temporal_attn_block2_supported(320, 5)
+    with pytest.raises(VdxError):
+        ops.temporal_attn_block2(torch.zeros(20, 320, dtype=torch.float16, device=gpu), torch.zeros(16, dtype=torch.float16, device=gpu), B=1, F=4, HW=5)
     t = torch.zeros(5 * 4, 320, dtype=torch.float16, device=gpu)
     v = torch.zeros(320, dtype=torch.float16, device=gpu)
     w = torch.zeros(16, dtype=torch.float16, device=gpu)

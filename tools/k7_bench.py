@@ -48,15 +48,24 @@ for inner, name in ((320, "level 0"), (512, "transformer_in")):
         def fused():
             ops.temporal_attn_block(t, gamma, beta, pq, po, bo, B=B, F=F, HW=HW, scale=0.125, out=out)
 
+        blob = packing.pack_k7b(wq, wk, wv, wo, gamma, beta, bo, 0.125).contiguous() if inner in packing.K7B_WIDTHS else None
+
+        def fused2():
+            ops.temporal_attn_block2(t, blob, B=B, F=F, HW=HW, out=out)
+
         def unfused():
             ln = ops.layernorm(t, gamma, beta, M=M)
             qkv = ops.gemm(ln, wqkv, M=M)
             o = ops.temporal_attn(qkv, B=B, F=F, HW=HW, heads=heads, scale=0.125)
             ops.gemm(o, wo, M=M, bias=bo, residual=t, out=out)
 
-        r = bench({"fused": fused, "unfused": unfused})
+        fns = {"fused": fused, "unfused": unfused}
+        if blob is not None:
+            fns["fused2"] = fused2
+        r = bench(fns)
         fl = 2.0 * M * 4 * inner * inner + 4.0 * M * F * inner
         print(f"{name:15s} inner {inner} F {F:2d} M {M:7d}: fused {r['fused']:.3f} ms ({fl / r['fused'] / 1e9:6.0f} TFLOP/s, "
-              f"{2 * M * inner * 2 / r['fused'] / 1e6:5.0f} GB/s algorithmic)   un-fused chain {r['unfused']:.3f} ms   x{r['unfused'] / r['fused']:.2f}",
+              f"{2 * M * inner * 2 / r['fused'] / 1e6:5.0f} GB/s algorithmic)   un-fused chain {r['unfused']:.3f} ms   x{r['unfused'] / r['fused']:.2f}"
+              + (f"   second design {r['fused2']:.3f} ms ({fl / r['fused2'] / 1e9:6.0f} TFLOP/s)" if blob is not None else ""),
               flush=True)
         del t, out
