@@ -16,8 +16,14 @@
 //   * the weight stream is cut into 8 KB units ([8 tiles][16 rows][32 k]) in a 5-unit ring that fills the 160 KB of
 //     LDS exactly beside the 120 KB row image; a K step is 64 deep (q|k: 2 units, 48 MFMAs per barrier; v: 1 unit).
 //
+//   * the kernel is PERSISTENT: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; while the output projection of a
+//     tile runs (it reads no row image), the rows of the NEXT tile are copied into the image by LDS-DMA (per-lane source
+//     address = row gather + XOR swizzle, no register) and centred / scaled in place behind the projection's MFMAs;
+//     the weight stream runs on across the tile boundary;
+//   * the scores and the softmax of a head (vector work) sit inside the first v steps of that head.
+//
 // Geometry (inner 320): 4 waves, one per SIMD, each owning a row group of 48 rows = G pixels x F frames (G = 48 / F)
-// for the whole tile; nothing a wave reads of the row image is written by another wave.
+// for the whole tile; nothing a wave reads of the row image is written by another wave (so the image needs no barrier).
 #include "vdx_common.h"
 #include <utility>
 
@@ -25,6 +31,11 @@ namespace {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) char lchar;                 // LDS addresses as 32-bit arithmetic: a constant
+typedef __attribute__((address_space(3))) f16x8 lf16x8;               // term then folds into the DS offset field
+typedef __attribute__((address_space(1))) f16 gf16;                   // explicit global pointers: a pointer the optimiser
+typedef __attribute__((address_space(1))) f16x8 gf16x8;               // cannot trace becomes a FLAT access (counts on both
+typedef __attribute__((address_space(1))) f32x4 gf32x4;               // counters, completes out of order)
 
 // workgroup barrier the COMPILER also treats as a memory barrier (LLVM models s_barrier as touching no memory)
 __device__ __forceinline__ void wg_barrier() {
@@ -49,9 +60,50 @@ struct K7BP {
     int G;               // pixels per row group = 48 / F
     int gpb;             // row groups per batch item = ceil(S / G)
     int ngroups;         // B * gpb
+    int ntiles;          // ceil(ngroups / 4)
     int fmagic;          // ceil(65536 / F): row / F == (row * fmagic) >> 16 for row < 64
     float eps;
 };
+
+// stores of rows that do not exist (last tile) go here, so that every epilogue issues the same number of stores and the
+// counted s_waitcnt of the next step stays exact
+static __device__ __attribute__((aligned(16))) u32x4 g_dump_page[64 + 64];     // lane * 16 bytes + up to 2 * INNER bytes of column offset
+
+__device__ __forceinline__ float dpp_add8(float v) {        // sum over the 8 lanes that share a row (lane & ~7)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+// value of lanes l, l^16, l^32, l^48 combined (the four lane quads that hold one query's keys): two VALU swaps, no LDS
+#ifdef K7B_SHFL
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+#else
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second;
+// v_permlane32_swap the upper half of the first with the lower half of the second.  Fed the same value twice, the two
+// results together hold the value of both partners in every lane.  Inline asm, not the builtins: hipcc (ROCm 7.2) folds
+// `r[0] op r[1]` of the builtin to `r[0] op r[0]` (seen in the ISA as v_add_f32 v, a0, a0 — the reduction is then a
+// no-op).  The s_nop covers the VALU-write -> permlane-read hazard (2 wait states), which nothing pads inside asm.
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float quad_max(float v) {
+    float a = v, b = v;
+    swap16(a, b);
+    a = fmaxf(a, b);
+    b = a;
+    swap32(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    float a = v, b = v;
+    swap16(a, b);
+    a = a + b;
+    b = a;
+    swap32(a, b);
+    return a + b;
+}
+#endif
 
 template <int INNER>
 struct K7B {
@@ -69,13 +121,19 @@ struct K7B {
     static constexpr int NSTEP = P1S + NCG * HEADS;       // the output projection contracts head by head (K = 64)
     static constexpr int UPH = 3 * KM;                    // units of one head in the q|k|v stream
     static constexpr int CPL = INNER / 64;                // 16-byte chunks per lane in P0 (8 lanes per row)
+    static constexpr int CPR = INNER / 8;                 // 16-byte chunks per row
+    static constexpr int NPS = 6;                         // P0 passes of 8 rows
+    static constexpr int PPP = 8 * RB / 1024;             // DMA pieces per pass
     static constexpr bool SW16 = (INNER / 8) % 16 == 0;
     static_assert(KS % 2 == 0 && (INNER % 128 == 0 || INNER % 128 == 64), "geometry");
     static_assert(XB + NU * UB <= 160 * 1024, "LDS budget");
+    static_assert((8 * RB) % 1024 == 0 && !SW16, "a pass of 8 rows is a whole number of 1 KB DMA pieces; the XOR stays inside a row");
+    static_assert(NCG == 3 && NPS <= HEADS + 1, "the next tile's rows are fetched behind the first column groups and normalised behind the later ones");
 
-    // ---- the static schedule of a tile: step s consumes units [ub(s), ub(s+1)) of the weight stream
+    // ---- the static schedule of a tile: step s consumes units [ub(s), ub(s+1)) of the weight stream; the stream runs
+    // on into the next tile (s >= NSTEP: the same schedule again)
     static constexpr int kind(int s) { return s < P1S ? ((s % HSTEPS) < KM ? 0 : 1) : 2; }        // 0 q|k, 1 v, 2 out
-    static constexpr int ub(int s) {
+    static constexpr int ub1(int s) {
         if (s <= P1S) {
             const int hs = s / HSTEPS, r = s % HSTEPS;
             return UPH * hs + (r < KM ? 2 * r : 2 * KM + (r - KM));
@@ -83,14 +141,48 @@ struct K7B {
         const int v = s - P1S, c = v / HEADS, m = v % HEADS;
         return UPH * HEADS + (c < NCGF ? 2 * HEADS * c + 2 * m : 2 * HEADS * NCGF + (v - NCGF * HEADS));
     }
-    static constexpr int NUNITS = ub(NSTEP);
+    static constexpr int NUNITS = ub1(NSTEP);
+    static constexpr int ub(int s) { return s <= NSTEP ? ub1(s) : NUNITS + ub1(s - NSTEP); }
     // units issued once step s has freed its own (s = -1: before the first step): as far ahead as the ring allows
-    static constexpr int hm(int s) { return ub(s + 1) + NU < NUNITS ? ub(s + 1) + NU : NUNITS; }
-    // DMA pieces (two per wave and unit) that may still be in flight when step s waits for the units of step s+1
-    static constexpr int inflight(int s) { return hm(s - 1) > ub(s + 2) ? 2 * (hm(s - 1) - ub(s + 2)) : 0; }
+    static constexpr int hm(int s) { return ub(s + 1) + NU; }
     static_assert(NUNITS % NU == 0, "the ring position of a unit must not depend on the tile");
 
-    __device__ static __forceinline__ int swz(int row) { return SW16 ? (row & 15) : ((row >> 1) & 7); }
+    // ---- every vector-memory instruction a wave issues, in order, so that the step's s_waitcnt vmcnt(N) is exact:
+    // N = the instructions YOUNGER than the last DMA piece the step needs.  After the weight units of step s-1's
+    // issue point come, in this order: the row pieces of the next tile issued there, the stores of a column group's
+    // epilogue (end of step s-1), and the loads at the top of step s (q bias of the next head, output bias of the next
+    // column group, residual rows).  All of them are unconditional and opaque to the optimiser (see opaque()).
+    static constexpr int xp(int s) { return s >= P1S && s < P1S + NPS ? PPP : 0; }                 // row pieces issued in step s
+    // pass ps is normalised at least five steps after its pieces were issued (the step waits in between retire every
+    // older DMA), and never in the last step of a column group, where the residual rows are in registers
+    static constexpr int p0_pass_of(int s) {
+        const int v = s - P1S - HEADS;              // steps into the second column group
+        if (v < 0 || v % HEADS == HEADS - 1) return -1;
+        const int ps = v - v / HEADS;
+        return ps < NPS ? ps : -1;
+    }
+    static constexpr int nt_of(int c) { return c < NCGF ? 8 : 4; }
+    static constexpr int first_of(int c) { return P1S + c * HEADS; }
+    static constexpr int n_bq(int s) { return kind(s) == 1 && s % HSTEPS == HSTEPS - 1 && s + 1 < P1S ? 4 : (s == NSTEP - 1 ? 4 : 0); }
+    static constexpr int n_bias(int s) {      // bias of column group c: one step before the group starts
+        for (int c = 0; c < NCG; ++c) if (s == first_of(c) - 1) return nt_of(c);
+        return 0;
+    }
+    static constexpr int n_res(int s) {       // residual rows of column group c: at the top of its last step
+        for (int c = 0; c < NCG; ++c) if (s == first_of(c) + HEADS - 1) return 3 * nt_of(c) / 2;
+        return 0;
+    }
+    static constexpr int n_st(int s) {        // stores of the epilogue that ran at the end of step s
+        for (int c = 0; c < NCG; ++c) if (s == first_of(c) + HEADS - 1) return 3 * nt_of(c) / 2;
+        return 0;
+    }
+    static constexpr int prev(int s) { return s == 0 ? NSTEP - 1 : s - 1; }
+    static constexpr int younger(int s) { return xp(prev(s)) + n_st(prev(s)) + n_bq(s) + n_bias(s) + n_res(s); }
+    // DMA pieces (two per wave and unit) + other instructions that may still be in flight when step s waits for the
+    // units of step s+1
+    static constexpr int inflight(int s) { return 2 * (hm(s - 1) - ub(s + 2)) + younger(s); }
+
+    __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
     struct Frag {
         f16x8 w[8], x[3];
@@ -101,29 +193,42 @@ struct K7B {
         f32x4 acc[3][8];                         // output projection: [col][row]
         f16x8 oh[HEADS][3][2];                   // the heads' outputs as B operands: [time slot][row tile][k step of the head]
         f32x4 bqv[4];
+        f16x4 qh[3][4], kh[3][4];                // q, k of the current head as fp16 MFMA operands
         f16x4 pt[3][3];                          // P^T of the current head: [query tile][key tile]
         f16x8 rv[3][4];                          // residual rows of the current column group
-        f32x4 bv[4][2];                          // its output bias
-        long long grow[3];
+        f32x4 bv[8];                             // its output bias, the projection's initial accumulator
+        const gf16* resp[3];                     // this lane's residual rows (+ 8*q4), or the dump page
+        gf16* outp[3];                           // this lane's output rows (+ 8*q4), or the dump page
     };
 
     const K7BP& p;
     char* smem;
-    int lane, n16, q4, wave, rot, woff, gi;
+    lchar* lds;                                  // the same, as an LDS pointer
+    int lane, n16, q4, wave, rot;
+    int woffb, xb[2];                            // LDS byte addresses: weight fragment base, row-image fragment bases (k step parity)
+    int gi, gin;                                 // this wave's row group in this tile / the next tile
     int qpix[3], kpix[3][4], need;
 
-    __device__ __forceinline__ K7B(const K7BP& p_, char* s) : p(p_), smem(s) {}
+    __device__ __forceinline__ K7B(const K7BP& p_, char* s) : p(p_), smem(s), lds((lchar*)s) {}
+
+    // a value the optimiser cannot see through: loads addressed with it are neither hoisted out of the tile loop nor
+    // merged — every source-level load below is exactly one instruction per tile (the wait counts rely on it)
+    __device__ static __forceinline__ int opaque(int v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
 
     // ---- weight stream
     template <int U>
     __device__ __forceinline__ const char* unit_src() const {
-        if constexpr (U < UPH * HEADS) {
-            constexpr int hs = U / UPH, w = U % UPH;
+        constexpr int u = U % NUNITS;
+        if constexpr (u < UPH * HEADS) {
+            constexpr int hs = u / UPH, w = u % UPH;
             int h = hs + rot;
             if (h >= HEADS) h -= HEADS;
             return p.wqkv + (size_t)(h * UPH + w) * UB;
         } else {
-            constexpr int v = U - UPH * HEADS;
+            constexpr int v = u - UPH * HEADS;
             if constexpr (v < 2 * HEADS * NCGF) {
                 constexpr int cg = v / (2 * HEADS), r = v % (2 * HEADS), hs = r / 2, kk = r % 2;
                 int h = hs + rot;
@@ -152,17 +257,94 @@ struct K7B {
         }
     }
 
-    __device__ __forceinline__ f16x8 xfrag(int i, int ks) const {
-        const int row = wave * 48 + 16 * i + n16;
-        return *(const f16x8*)(smem + row * RB + (((4 * ks + q4) ^ swz(row)) << 4));
-    }
-    __device__ __forceinline__ f16x8 wfrag(int unit, int tile) const {
-        return *(const f16x8*)(smem + XB + (unit % NU) * UB + tile * 1024 + woff);
+    // global row index of local row r (0..47) of row group g4 (clamped to row 0 when it does not exist) and whether it
+    // exists; branch-free: every lane computes an address, the caller selects
+    __device__ __forceinline__ bool grow_of(int g4, int r, long long& gr) const {
+        const int g = (r * p.fmagic) >> 16, f = r - g * p.F;
+        const int b = g4 / p.gpb, pix = (g4 - b * p.gpb) * p.G + g;            // (g4 is wave-uniform: scalar division)
+        const bool ok = g4 < p.ngroups && pix < p.S;
+        gr = ok ? (long long)((b * p.F + f) * p.S + pix) : 0ll;
+        return ok;
     }
 
-    // fragments of half KK (one MFMA k step) of step S
-    template <int S, int KK>
+    // ---- rows of row group g4 -> the wave's part of the image, pass PS (8 rows = PPP pieces of 1 KB), by LDS-DMA.
+    // The destination is linear (wave-uniform base + lane * 16); the XOR swizzle of the image and the row gather
+    // (a row's frames are S rows apart) are in the per-lane SOURCE address.  Rows that do not exist read the zero page.
+    template <int PS>
+    __device__ __forceinline__ void issue_rows(int g4) {
+        const char* zp = (const char*)g_zero_page;
+#pragma unroll
+        for (int pc = 0; pc < PPP; ++pc) {
+            const int ci = pc * 64 + lane;                       // chunk inside the pass
+            const int r8 = (ci * (65536 / CPR + 1)) >> 16;       // ci / CPR (exact for ci < 8 * CPR)
+            const int pos = ci - r8 * CPR;
+            const int r = 8 * PS + r8;
+            long long gr;
+            const bool ok = grow_of(g4, r, gr);
+            const char* rowp = (const char*)(p.t + gr * p.ldt) + ((pos ^ swz(r)) << 4);
+            const char* src = ok ? rowp : zp;
+            char* dst = smem + (wave * 48 + 8 * PS) * RB + pc * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        }
+    }
+    // P0 of pass PS, in place: centre and scale the 8 rows (8 lanes per row, CPL chunks per lane).  fp32 statistics:
+    // the mean from the row sum, the variance from the squares of (x - mean_h) with mean_h the mean rounded to fp16
+    // (the differences are then exact to fp16 relative precision, whatever the mean) corrected by (mean - mean_h)^2;
+    // the result x * rstd - mean * rstd is formed in fp32 and rounded once.  gamma / beta live in the weights.
+    template <int PS>
+    __device__ __forceinline__ void p0_pass() {
+        const int sub = lane & 7, r = 8 * PS + (lane >> 3);
+        const int row = wave * 48 + r;
+        lchar* base = lds + row * RB + ((sub ^ swz(row)) << 4);        // chunk (sub + 8j) ^ sw = 8j + (sub ^ sw)
+        f16x8 v[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[j] = *(const lf16x8*)(base + 128 * j);
+        const f16x2 ones = (f16x2){(f16)1.f, (f16)1.f};
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum = __builtin_amdgcn_fdot2((f16x2){v[j][2 * e], v[j][2 * e + 1]}, ones, sum, false);
+        sum = dpp_add8(sum);
+        const float mean = sum * (1.0f / INNER);
+        const f16 mh = (f16)mean;
+        const float dm = mean - (float)mh;
+        const f16x2 nm = (f16x2){(f16)-mh, (f16)-mh};
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f16x2 d = (f16x2){v[j][2 * e], v[j][2 * e + 1]} + nm;
+                ss = __builtin_amdgcn_fdot2(d, d, ss, false);
+            }
+        ss = dpp_add8(ss);
+        const float var = fmaxf(ss * (1.0f / INNER) - dm * dm, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)fmaf((float)v[j][e], rstd, nmr);
+            *(lf16x8*)(base + 128 * j) = o;
+        }
+    }
+
+    // row-image fragment: row 16*i + n16 of the wave's group, chunk (4*ks + q4) ^ swz(row).  swz(row) = (row >> 1) & 7 does
+    // not depend on i (16*i and 48*wave are multiples of 16) and only touches the low 3 bits of the chunk, so the address
+    // is xb[ks & 1] + a constant
+    __device__ __forceinline__ f16x8 xfrag(int i, int ks) const {
+        return *(const lf16x8*)(lds + xb[ks & 1] + (16 * i * RB + 128 * (ks >> 1)));
+    }
+    __device__ __forceinline__ f16x8 wfrag(int unit, int tile) const {
+        return *(const lf16x8*)(lds + woffb + ((unit % NU) * UB + tile * 1024));
+    }
+
+    // fragments of half KK (one MFMA k step) of step S (S may be NSTEP: step 0 of the next tile)
+    template <int S_, int KK>
     __device__ __forceinline__ void read_half(Frag& f) const {
+        constexpr int S = S_ % NSTEP;
         constexpr int kd = kind(S), u0 = ub(S);
         if constexpr (kd == 0) {
             constexpr int m = S % HSTEPS;
@@ -196,7 +378,6 @@ struct K7B {
     __device__ __forceinline__ void mma_half(State& st, const Frag& f) {
         constexpr int kd = kind(S);
         const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int nm = 0;
         if constexpr (kd == 0) {
             constexpr bool Z = (S % HSTEPS) == 0 && KK == 0;
 #pragma unroll
@@ -206,7 +387,6 @@ struct K7B {
                     st.aq[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[j], f.x[i], Z ? st.bqv[j] : st.aq[i][j], 0, 0, 0);
                     st.ak[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[4 + j], f.x[i], Z ? zero4 : st.ak[i][j], 0, 0, 0);
                 }
-            nm = 24;
         } else if constexpr (kd == 1) {
             constexpr bool Z = (S % HSTEPS) == KM && KK == 0;
 #pragma unroll
@@ -214,17 +394,15 @@ struct K7B {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
                     st.av[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.x[i], f.w[j], Z ? zero4 : st.av[i][j], 0, 0, 0);
-            nm = 12;
         } else {
             constexpr int v = S - P1S, c = v / HEADS, hs = v % HEADS;
             constexpr bool Z = hs == 0 && KK == 0;
-            constexpr int NT = c < NCGF ? 8 : 4;
+            constexpr int NT = nt_of(c);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    st.acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[j], st.oh[hs][i][KK], Z ? zero4 : st.acc[i][j], 0, 0, 0);
-            nm = 3 * NT;
+                    st.acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[j], st.oh[hs][i][KK], Z ? st.bv[j] : st.acc[i][j], 0, 0, 0);
         }
         // issue order (a compile-time directive): one memory instruction after every MFMA until they are used up
 #pragma unroll
@@ -237,77 +415,69 @@ struct K7B {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        (void)nm;
     }
 
-    static constexpr int nds(int s) { return s >= NSTEP ? 0 : kind(s) == 0 ? 11 : kind(s) == 1 ? 7 : ((s - P1S) / HEADS < NCGF ? 8 : 4); }
-
-    // global row of local row r (0..47) of this wave's row group, or -1
-    __device__ __forceinline__ long long grow_of(int r) const {
-        const int g = (r * p.fmagic) >> 16, f = r - g * p.F;
-        const int b = gi / p.gpb, pix = (gi - b * p.gpb) * p.G + g;
-        if (gi >= p.ngroups || pix >= p.S) return -1;
-        return ((long long)b * p.F + f) * p.S + pix;
+    static constexpr int nds(int s_) {
+        const int s = s_ % NSTEP;
+        return kind(s) == 0 ? 11 : kind(s) == 1 ? 7 : nt_of((s - P1S) / HEADS);
     }
 
     // ---- attention of the head in time slot HS on the wave's 48 rows, all in registers.
-    // Part 1, after the q|k pass: S^T = K Q^T (query on the lane), softmax over the keys -> P^T as fp16 (18 registers);
-    // the q and k accumulators are dead from here on, the v pass runs with 48.
-    template <int HS>
-    __device__ __forceinline__ void attn_scores(State& st) {
-        f16x4 qh[3][4], kh[3][4];
+    // After the q|k pass: q, k as fp16 operands (the accumulators are dead from here on, the v pass runs with 48).
+    __device__ __forceinline__ void attn_cvt_qk(State& st) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    qh[i][j][e] = (f16)st.aq[i][j][e];
-                    kh[i][j][e] = (f16)st.ak[i][j][e];
+                    st.qh[i][j][e] = (f16)st.aq[i][j][e];
+                    st.kh[i][j][e] = (f16)st.ak[i][j][e];
                 }
-#pragma unroll
-        for (int qt = 0; qt < 3; ++qt) {
-            f32x4 sc[3];
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
-                sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if ((need >> (3 * qt + kt)) & 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kh[kt][j], qh[qt][j], sc[kt], 0, 0, 0);
-                }
-            }
-            float mx = -1.0e30f;
-            bool ok[3][4];
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool pure = (need >> (9 + 3 * qt + kt)) & 1;       // wave-uniform
-                    ok[kt][e] = pure || (((need >> (3 * qt + kt)) & 1) && kpix[kt][e] == qpix[qt]);
-                    mx = fmaxf(mx, ok[kt][e] ? sc[kt][e] : -1.0e30f);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float rs = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sc[kt][e] = ok[kt][e] ? __builtin_amdgcn_exp2f(sc[kt][e] - mx) : 0.f;     // (the scale is in W_q)
-                    rs += sc[kt][e];
-                }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            const float inv = 1.0f / rs;
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) st.pt[qt][kt][e] = (f16)(sc[kt][e] * inv);
-        }
     }
-    // Part 2, after the v pass: O^T[d][query] = V^T P^T: lane = query row, registers e = d 16*dt + 4*q4 + e.  Two d tiles
-    // side by side are one B operand of the output projection (k index of W_o permuted to match: packing.pack_k7b).
+    // Scores of query tile QT: S^T = K Q^T (query on the lane), softmax over the keys -> P^T as fp16.  Runs inside the
+    // head's v steps, beside their MFMAs.
+    template <int QT>
+    __device__ __forceinline__ void attn_scores(State& st) {
+        f32x4 sc[3];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((need >> (3 * QT + kt)) & 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(st.kh[kt][j], st.qh[QT][j], sc[kt], 0, 0, 0);
+            }
+        }
+        float mx = -1.0e30f;
+        bool ok[3][4];
+        const int qp = opaque(qpix[QT]);      // (recomputed per head: 36 compare masks kept across the heads do not fit the SGPRs)
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool pure = (need >> (9 + 3 * QT + kt)) & 1;       // wave-uniform
+                ok[kt][e] = pure || (((need >> (3 * QT + kt)) & 1) && kpix[kt][e] == qp);
+                mx = fmaxf(mx, ok[kt][e] ? sc[kt][e] : -1.0e30f);
+            }
+        mx = quad_max(mx);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc[kt][e] = ok[kt][e] ? __builtin_amdgcn_exp2f(sc[kt][e] - mx) : 0.f;     // (the scale is in W_q)
+                rs += sc[kt][e];
+            }
+        rs = quad_sum(rs);
+        const float inv = 1.0f / rs;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st.pt[QT][kt][e] = (f16)(sc[kt][e] * inv);
+    }
+    // After the v pass: O^T[d][query] = V^T P^T: lane = query row, registers e = d 16*dt + 4*q4 + e.  Two d tiles side
+    // by side are one B operand of the output projection (k index of W_o permuted to match: packing.pack_k7b).
     template <int HS>
     __device__ __forceinline__ void attn_pv(State& st) {
         f16x4 vh[3][4];
@@ -336,163 +506,98 @@ struct K7B {
             }
     }
 
-    // q bias of the head in time slot HS (its d = 16*j + 4*q4 + e on the accumulator registers)
+    // q bias of the head in time slot HS: the initial accumulator of its q (d = 16*j + 4*q4 + e on the registers)
     template <int HS>
     __device__ __forceinline__ void load_bq(State& st) {
         int h = HS + rot;
         if (h >= HEADS) h -= HEADS;
+        const int o = opaque(h * 64 + 4 * q4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st.bqv[j] = *(const f32x4*)(p.bq + h * 64 + 16 * j + 4 * q4);
+        for (int j = 0; j < 4; ++j) st.bqv[j] = *(const gf32x4*)((const __attribute__((address_space(1))) float*)p.bq + o + 16 * j);
     }
-
-    // residual rows of column group C: requested at the start of the group's K loop, consumed after it
-    template <int C>
-    __device__ __forceinline__ void load_residual(State& st) {
-        constexpr int NT = C < NCGF ? 8 : 4;
-        const f16* zp = (const f16*)g_zero_page;
-        const int cb = C * 128 + 8 * q4;
-#pragma unroll
-        for (int a = 0; a < NT / 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                st.rv[i][a] = *(const f16x8*)(st.grow[i] >= 0 ? p.t + st.grow[i] * p.ldt + cb + 32 * a : zp);
-    }
+    // output bias of column group C: the initial accumulator of the projection (tile 2a + jj, register e: column
+    // 32a + 8*q4 + 4*jj + e of the group)
     template <int C>
     __device__ __forceinline__ void load_bias(State& st) {
-        constexpr int NT = C < NCGF ? 8 : 4;
-        const int cb = C * 128 + 8 * q4;
+        const int o = opaque(C * 128 + 8 * q4);
 #pragma unroll
-        for (int a = 0; a < NT / 2; ++a) {
-            st.bv[a][0] = *(const f32x4*)(p.bo2 + cb + 32 * a);
-            st.bv[a][1] = *(const f32x4*)(p.bo2 + cb + 32 * a + 4);
+        for (int j = 0; j < nt_of(C); ++j) st.bv[j] = *(const gf32x4*)((const __attribute__((address_space(1))) float*)p.bo2 + o + 32 * (j / 2) + 4 * (j % 2));
+    }
+    // residual rows of column group C: requested at the top of the group's last K step, consumed after it
+    template <int C>
+    __device__ __forceinline__ void load_residual(State& st) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const gf16* src = st.resp[i] + opaque(0);
+#pragma unroll
+            for (int a = 0; a < nt_of(C) / 2; ++a) st.rv[i][a] = *(const gf16x8*)(src + C * 128 + 32 * a);
         }
     }
     // tile pair (2a, 2a+1) gives this lane 8 consecutive columns 32a + 8*q4 .. +7 of row n16 (+16i)
     template <int C>
     __device__ __forceinline__ void epilogue(State& st) {
-        constexpr int NT = C < NCGF ? 8 : 4;
-        const int cb = C * 128 + 8 * q4;
 #pragma unroll
-        for (int a = 0; a < NT / 2; ++a) {
-            const f32x4 b0 = st.bv[a][0], b1 = st.bv[a][1];
+        for (int a = 0; a < nt_of(C) / 2; ++a)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 f16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (f16)(st.acc[i][2 * a][e] + b0[e] + (float)st.rv[i][a][e]);
-                    o[4 + e] = (f16)(st.acc[i][2 * a + 1][e] + b1[e] + (float)st.rv[i][a][4 + e]);
+                    o[e] = (f16)(st.acc[i][2 * a][e] + (float)st.rv[i][a][e]);
+                    o[4 + e] = (f16)(st.acc[i][2 * a + 1][e] + (float)st.rv[i][a][4 + e]);
                 }
-                if (st.grow[i] >= 0) *(f16x8*)(p.out + st.grow[i] * p.ldo + cb + 32 * a) = o;
+                *(gf16x8*)(st.outp[i] + C * 128 + 32 * a) = o;
             }
-        }
     }
 
     // ---- one step of the tile.  At its top the fragments of its first half are in registers (st.fa).
     template <int S>
     __device__ __forceinline__ void step(State& st) {
         constexpr int kd = kind(S);
-        // q bias of the NEXT head: requested a step before its first MFMAs start from it
-        if constexpr (kd == 1 && S % HSTEPS == HSTEPS - 1 && S + 1 < P1S) load_bq<S / HSTEPS + 1>(st);
-        if constexpr (kd == 2 && (S - P1S) % HEADS == 0) load_residual<(S - P1S) / HEADS>(st);
-        if constexpr (kd == 2 && (S - P1S) % HEADS == HEADS - 1) load_bias<(S - P1S) / HEADS>(st);
+        // loads of later steps, requested here (counted by younger(S))
+        if constexpr (n_bq(S) > 0) load_bq<(S == NSTEP - 1 ? 0 : S / HSTEPS + 1)>(st);
+        if constexpr (n_bias(S) > 0) load_bias<(S + 1 - P1S) / HEADS>(st);
+        if constexpr (n_res(S) > 0) load_residual<(S - P1S) / HEADS>(st);
+        // vector work that rides on this step's MFMAs: the scores of the head (v steps 0..2), the next tile's rows
+        if constexpr (kd == 1 && S % HSTEPS - KM < 3) attn_scores<S % HSTEPS - KM>(st);
+        if constexpr (p0_pass_of(S) >= 0) p0_pass<p0_pass_of(S)>();
         // second half's fragments behind the first half's MFMAs
         read_half<S, 1>(st.fb);
         mma_half<S, 0, nds(S), 0>(st, st.fa);
         // the units of step S+1 have landed for everyone, and nobody reads the units of step S any more
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S + 1 < NSTEP) {
-            wait_vm<inflight(S)>();
-            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): my reads of step S's units are done (builtin: the
-            asm volatile("" ::: "memory");           // compiler then knows st.fb is valid)
-            wg_barrier();
-            issue_range<hm(S - 1), hm(S)>();
-            read_half<S + 1, 0>(st.fa);
-        }
-        mma_half<S, 1, nds(S + 1), 2 * (hm(S) - hm(S - 1))>(st, st.fb);
+        wait_vm<inflight(S)>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): my reads of step S's units are done (builtin: the
+        asm volatile("" ::: "memory");           // compiler then knows st.fb is valid)
+        wg_barrier();
+        issue_range<hm(S - 1), hm(S)>();
+        if constexpr (xp(S) > 0) issue_rows<S - P1S>(gin);
+        read_half<S + 1, 0>(st.fa);
+        mma_half<S, 1, nds(S + 1), 2 * (hm(S) - hm(S - 1)) + xp(S)>(st, st.fb);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kd == 0 && S % HSTEPS == KM - 1) attn_scores<S / HSTEPS>(st);
+        if constexpr (kd == 0 && S % HSTEPS == KM - 1) attn_cvt_qk(st);
         if constexpr (kd == 1 && S % HSTEPS == HSTEPS - 1) attn_pv<S / HSTEPS>(st);
-        if constexpr (kd == 2 && (S - P1S) % HEADS == HEADS - 1) epilogue<(S - P1S) / HEADS>(st);
+        if constexpr (n_st(S) > 0) epilogue<(S - P1S) / HEADS>(st);
     }
     template <int... S>
     __device__ __forceinline__ void steps(State& st, std::integer_sequence<int, S...>) {
         (step<S>(st), ...);
     }
+    template <int... PS>
+    __device__ __forceinline__ void first_rows(std::integer_sequence<int, PS...>) {
+        (issue_rows<PS>(gi), ...);
+        wait_vm<0>();
+        (p0_pass<PS>(), ...);
+    }
 
-    __device__ __forceinline__ void run() {
-        const int tid = threadIdx.x;
-        lane = tid & 63;
-        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __device__ __forceinline__ void set_lane_constants() {
         n16 = lane & 15;
         q4 = lane >> 4;
-        {
-            const int g = (0x1320 >> (4 * (n16 >> 2))) & 3;      // g = [0, 2, 3, 1][n >> 2]
-            woff = n16 * 64 + ((q4 ^ g) << 4);
-        }
-        gi = blockIdx.x * 4 + wave;                             // this wave's row group
-        rot = (blockIdx.x >> 3) % HEADS;                        // blocks b and b+8 share an XCD (see tattn_fused.hip)
-        const f16* zp = (const f16*)g_zero_page;
-
-        // the weight stream starts before the rows are even loaded
-        issue_range<0, hm(-1)>();
-        State st;
-        load_bq<0>(st);
-
-        // ---- P0: rows -> centred and scaled (fp32 statistics, two passes over registers) -> X (fp16, swizzled) in LDS.
-        // 8 lanes per row, CPL chunks of 8 channels per lane.  gamma / beta live in the weights.
-        {
-            const int sub = lane & 7;
-            constexpr int NPS = 48 / 8;
-            f16x8 v[NPS][CPL];
-            long long grs[NPS];
-#pragma unroll
-            for (int ps = 0; ps < NPS; ++ps) {
-                const int r = 8 * ps + (lane >> 3);
-                grs[ps] = grow_of(r);
-                const f16* src = grs[ps] >= 0 ? p.t + grs[ps] * p.ldt + 8 * sub : zp;
-                const int stp = grs[ps] >= 0 ? 64 : 0;
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) v[ps][j] = *(const f16x8*)(src + j * stp);
-            }
-#pragma unroll
-            for (int ps = 0; ps < NPS; ++ps) {
-                const int r = 8 * ps + (lane >> 3);
-                float sum = 0.f;
-#pragma unroll
-                for (int j = 0; j < CPL; ++j)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sum += (float)v[ps][j][e];
-                sum += __shfl_xor(sum, 1, 64);
-                sum += __shfl_xor(sum, 2, 64);
-                sum += __shfl_xor(sum, 4, 64);
-                const float mean = sum * (1.0f / INNER);
-                float var = 0.f;
-#pragma unroll
-                for (int j = 0; j < CPL; ++j)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float d = (float)v[ps][j][e] - mean;
-                        var += d * d;
-                    }
-                var += __shfl_xor(var, 1, 64);
-                var += __shfl_xor(var, 2, 64);
-                var += __shfl_xor(var, 4, 64);
-                const float rstd = rsqrtf(var * (1.0f / INNER) + p.eps);
-                const float nmr = -mean * rstd;
-                const int row = wave * 48 + r;
-                char* dst = smem + row * RB;
-                const int sw = swz(row);
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    f16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = grs[ps] >= 0 ? (f16)fmaf((float)v[ps][j][e], rstd, nmr) : (f16)0.f;
-                    *(f16x8*)(dst + (((sub + 8 * j) ^ sw) << 4)) = o;
-                }
-            }
-        }
-
+        const int g = (0x1320 >> (4 * (n16 >> 2))) & 3;          // g = [0, 2, 3, 1][n >> 2]
+        woffb = XB + n16 * 64 + ((q4 ^ g) << 4);
+        const int row = wave * 48 + n16, sw = swz(row);
+        xb[0] = row * RB + ((q4 ^ sw) << 4);
+        xb[1] = row * RB + (((4 + q4) ^ sw) << 4);
         // pixel of my query rows / key rows inside the 48-row group (for the block-diagonal mask)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -500,6 +605,14 @@ struct K7B {
 #pragma unroll
             for (int e = 0; e < 4; ++e) kpix[i][e] = ((16 * i + 4 * q4 + e) * p.fmagic) >> 16;
         }
+    }
+
+    __device__ __forceinline__ void run() {
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        rot = (blockIdx.x >> 3) % HEADS;                        // blocks b and b+8 share an XCD (see tattn_fused.hip)
+        set_lane_constants();
         // 16-row tiles of the group that share no pixel need no score tile at all (F = 16: only the diagonal; F = 24:
         // 7 of 9): bit 3*qt + kt of `need` says query tile qt has a pixel in common with key tile kt (wave-uniform);
         // bit 9 + 3*qt + kt: both tiles lie inside ONE pixel, no mask
@@ -514,15 +627,44 @@ struct K7B {
             }
         need = __builtin_amdgcn_readfirstlane(need);
 
-#pragma unroll
-        for (int i = 0; i < 3; ++i) st.grow[i] = grow_of(16 * i + n16);
-
-        // the units of step 0 have landed for everyone (X is private to the wave: its own writes only need lgkmcnt)
-        wait_vm<2 * (hm(-1) - ub(1))>();
+        // ---- first tile: the weight stream, the tile's rows, the first q bias; everything has landed before the first
+        // step (so its counted wait finds nothing outstanding), the rows are centred and scaled in place
+        int tile = blockIdx.x;
+        gi = tile * 4 + wave;
+        State st;
+        issue_range<0, hm(-1)>();
+        load_bq<0>(st);
+        first_rows(std::make_integer_sequence<int, NPS>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wg_barrier();
         read_half<0, 0>(st.fa);
-        steps(st, std::make_integer_sequence<int, NSTEP>{});
+
+        for (;;) {
+            // Everything below is straight-line code per tile.  The lane constants are made opaque once per tile: the
+            // optimiser otherwise hoists every address that depends only on them (hundreds) out of this loop and
+            // spills them around it.
+            asm volatile("" : "+v"(lane));
+            asm volatile("" : "+s"(wave), "+s"(rot));
+            set_lane_constants();
+            const int next = tile + gridDim.x;
+            gin = next * 4 + wave;              // (past the last tile: every row reads the zero page)
+            // rows that do not exist (last tile) read and write the dump page: every tile issues the same instructions
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                long long gr;
+                const bool ok = grow_of(gi, 16 * i + n16, gr);
+                gf16* dump = (gf16*)g_dump_page + lane * 8;
+                const gf16* rp = (const gf16*)p.t + gr * p.ldt + 8 * q4;
+                gf16* op = (gf16*)p.out + gr * p.ldo + 8 * q4;
+                st.resp[i] = ok ? rp : dump;
+                st.outp[i] = ok ? op : dump;
+            }
+            steps(st, std::make_integer_sequence<int, NSTEP>{});
+            if (next >= p.ntiles) break;
+            tile = next;
+            gi = gin;
+        }
+        wait_vm<0>();        // (the stream ran on into a tile that does not exist: let its copies land before the LDS is released)
     }
 };
 
@@ -563,13 +705,17 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     p.G = 48 / F;
     p.gpb = (HW + p.G - 1) / p.G;
     p.ngroups = B * p.gpb;
+    p.ntiles = (p.ngroups + 3) / 4;
     p.fmagic = (65536 + F - 1) / F;
     p.eps = eps;
     constexpr int lds = T::XB + T::NU * T::UB;
     auto kern = tattn2_kernel<320>;
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr_rc != hipSuccess) return vdx_fail("temporal_attn_block2: cannot reserve %d bytes of LDS", lds);
-    const int tiles = (p.ngroups + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, (hipStream_t)stream, p);
+    // persistent grid: every workgroup walks the same number of tiles (+-1), one workgroup per CU at most
+    const int ncu = vdx_num_cus();
+    const int rounds = (p.ntiles + ncu - 1) / ncu;
+    const int grid = (p.ntiles + rounds - 1) / rounds;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return vdx_launch_status("vdx_temporal_attn_block2_f16");
 }

@@ -34,6 +34,17 @@ static inline int vdx_launch_status(const char* what) {
     return 0;
 }
 
+// compute units of the current device (persistent grids, tile-round pricing); 256 on MI355X
+static inline int vdx_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below fp16

@@ -523,12 +523,15 @@ def test_temporal_attn_block_fused(gpu, inner, B, Fr, HW):
 
 
 @pytest.mark.parametrize("B,Fr,HW", [(2, 24, 20), (1, 16, 7), (2, 12, 9), (1, 8, 5), (1, 24, 1), (2, 6, 33), (1, 48, 3),
-                                     (1, 1, 100), (2, 24, 301), (1, 16, 515), (2, 3, 64), (1, 2, 777)])
+                                     (1, 1, 100), (2, 24, 301), (1, 16, 515), (2, 3, 64), (1, 2, 777),
+                                     (2, 24, 1100), (1, 12, 4100), (3, 16, 2000)])
 def test_temporal_attn_block2_fused(gpu, B, Fr, HW):
     """K7, second design (csrc/tattn2.hip, inner 320): LayerNorm (folded into the packed weights) -> q|k -> scores ->
     v -> P.V -> to_out + bias + residual in one kernel, against the fp32 statement of the sub-block and
     against the un-fused kernels.  F in {24, 16, 12} (the BASELINE chunks) and other divisors of 48; pixel counts that do
-    not fill the last row group / the last block, and counts that give many blocks (every rotation of the head order)."""
+    not fill the last row group / the last block, counts that give many blocks (every rotation of the head order), and
+    counts of more than 256 tiles (a workgroup then walks several tiles: the next tile's rows are fetched and normalised
+    behind the output projection of the current one, the last round is ragged)."""
     ops, _ = _ops()
     from vdx import packing
     inner, heads = 320, 5
