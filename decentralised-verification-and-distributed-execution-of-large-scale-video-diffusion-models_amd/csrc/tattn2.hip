@@ -105,6 +105,24 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 #endif
 
+#ifdef K7B_STAMPS   // diagnostic build only: cycle totals per (step kind, segment) of wave 0; never in the product library
+static __device__ unsigned long long g_k7b_stamps[1024 * 16];
+extern "C" int vdx_debug_read_k7b_stamps(void* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_k7b_stamps), sizeof(g_k7b_stamps)) == hipSuccess ? 0 : -1;
+}
+#define K7B_T(idx)                                                                                     \
+    {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        unsigned long long now_;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        tsum[idx] += now_ - tlast;                                                                     \
+        tlast = now_;                                                                                  \
+    }
+#else
+#define K7B_T(idx)
+#endif
+
 template <int INNER>
 struct K7B {
     static constexpr int KS = INNER / 32;                 // MFMA k steps over the model width
@@ -124,10 +142,11 @@ struct K7B {
     static constexpr int CPR = INNER / 8;                 // 16-byte chunks per row
     static constexpr int NPS = 6;                         // P0 passes of 8 rows
     static constexpr int PPP = 8 * RB / 1024;             // DMA pieces per pass
-    static constexpr bool SW16 = (INNER / 8) % 16 == 0;
     static_assert(KS % 2 == 0 && (INNER % 128 == 0 || INNER % 128 == 64), "geometry");
     static_assert(XB + NU * UB <= 160 * 1024, "LDS budget");
-    static_assert((8 * RB) % 1024 == 0 && !SW16, "a pass of 8 rows is a whole number of 1 KB DMA pieces; the XOR stays inside a row");
+    static constexpr int NCB = INNER / 64;                // column blocks of 64 channels (= PPP: one DMA piece each)
+    static constexpr int RBB = NCB * 1024;                // bytes of one row block (8 rows)
+    static_assert(PPP == NCB && XB == 24 * RBB, "a DMA piece is one (row block, column block): 8 rows x 128 bytes");
     static_assert(NCG == 3 && NPS <= HEADS + 1, "the next tile's rows are fetched behind the first column groups and normalised behind the later ones");
 
     // ---- the static schedule of a tile: step s consumes units [ub(s), ub(s+1)) of the weight stream; the stream runs
@@ -154,7 +173,7 @@ struct K7B {
     // column group, residual rows).  All of them are unconditional and opaque to the optimiser (see opaque()).
     static constexpr int xp(int s) { return s >= P1S && s < P1S + NPS ? PPP : 0; }                 // row pieces issued in step s
     // pass ps is normalised at least five steps after its pieces were issued (the step waits in between retire every
-    // older DMA), and never in the last step of a column group, where the residual rows are in registers
+    // older DMA), and never in the last step of a column group (the epilogue follows)
     static constexpr int p0_pass_of(int s) {
         const int v = s - P1S - HEADS;              // steps into the second column group
         if (v < 0 || v % HEADS == HEADS - 1) return -1;
@@ -168,8 +187,8 @@ struct K7B {
         for (int c = 0; c < NCG; ++c) if (s == first_of(c) - 1) return nt_of(c);
         return 0;
     }
-    static constexpr int n_res(int s) {       // residual rows of column group c: at the top of its last step
-        for (int c = 0; c < NCG; ++c) if (s == first_of(c) + HEADS - 1) return 3 * nt_of(c) / 2;
+    static constexpr int n_res(int s) {       // residual rows of column group c: at the top of its second step
+        for (int c = 0; c < NCG; ++c) if (s == first_of(c) + 1) return 3 * nt_of(c) / 2;
         return 0;
     }
     static constexpr int n_st(int s) {        // stores of the epilogue that ran at the end of step s
@@ -182,7 +201,6 @@ struct K7B {
     // units of step s+1
     static constexpr int inflight(int s) { return 2 * (hm(s - 1) - ub(s + 2)) + younger(s); }
 
-    __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
     struct Frag {
         f16x8 w[8], x[3];
@@ -208,6 +226,9 @@ struct K7B {
     int woffb, xb[2];                            // LDS byte addresses: weight fragment base, row-image fragment bases (k step parity)
     int gi, gin;                                 // this wave's row group in this tile / the next tile
     int qpix[3], kpix[3][4], need;
+#ifdef K7B_STAMPS
+    unsigned long long tsum[16], tlast;
+#endif
 
     __device__ __forceinline__ K7B(const K7BP& p_, char* s) : p(p_), smem(s), lds((lchar*)s) {}
 
@@ -267,42 +288,44 @@ struct K7B {
         return ok;
     }
 
-    // ---- rows of row group g4 -> the wave's part of the image, pass PS (8 rows = PPP pieces of 1 KB), by LDS-DMA.
-    // The destination is linear (wave-uniform base + lane * 16); the XOR swizzle of the image and the row gather
-    // (a row's frames are S rows apart) are in the per-lane SOURCE address.  Rows that do not exist read the zero page.
+    // ---- The row image.  LDS layout: [row block of 8 rows][column block of 64 channels][8 rows][128 bytes]; inside the
+    // 128 bytes of a row the 16-byte chunk c sits at position c ^ (row & 7).  A (row block, column block) is 1 KB = one
+    // LDS-DMA piece whose lane L carries row L >> 3, position L & 7: the per-lane SOURCE address does the row gather (a
+    // row's frames are S rows apart) and the XOR; the column block is an immediate offset.  For the MFMA fragment reads
+    // (16 rows x 16 bytes per lane quad) the XOR makes every ds_read_b128 lane group hit 16 distinct slots of the
+    // 256-byte bank row; the in-place normalisation reads and writes whole pieces.
+    //
+    // rows of row group g4, pass PS (its 8 rows) -> the wave's part of the image, by LDS-DMA.  Rows that do not exist
+    // read the zero page (their values must stay finite: a masked key still multiplies a zero probability).
     template <int PS>
     __device__ __forceinline__ void issue_rows(int g4) {
+        const int r = 8 * PS + (lane >> 3);
+        long long gr;
+        const bool ok = grow_of(g4, r, gr);
+        const char* rowp = (const char*)(p.t + gr * p.ldt) + (((lane & 7) ^ (lane >> 3)) << 4);
         const char* zp = (const char*)g_zero_page;
+        const char* src = ok ? rowp : zp;
+        const int cstep = ok ? 128 : 0;
+        char* dst = smem + (wave * 6 + PS) * RBB;
 #pragma unroll
-        for (int pc = 0; pc < PPP; ++pc) {
-            const int ci = pc * 64 + lane;                       // chunk inside the pass
-            const int r8 = (ci * (65536 / CPR + 1)) >> 16;       // ci / CPR (exact for ci < 8 * CPR)
-            const int pos = ci - r8 * CPR;
-            const int r = 8 * PS + r8;
-            long long gr;
-            const bool ok = grow_of(g4, r, gr);
-            const char* rowp = (const char*)(p.t + gr * p.ldt) + ((pos ^ swz(r)) << 4);
-            const char* src = ok ? rowp : zp;
-            char* dst = smem + (wave * 48 + 8 * PS) * RB + pc * 1024;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        }
+        for (int cb = 0; cb < NCB; ++cb)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + cb * cstep), (lptr_t)(dst + cb * 1024), 16, 0, 0);
     }
-    // P0 of pass PS, in place: centre and scale the 8 rows (8 lanes per row, CPL chunks per lane).  fp32 statistics:
-    // the mean from the row sum, the variance from the squares of (x - mean_h) with mean_h the mean rounded to fp16
-    // (the differences are then exact to fp16 relative precision, whatever the mean) corrected by (mean - mean_h)^2;
-    // the result x * rstd - mean * rstd is formed in fp32 and rounded once.  gamma / beta live in the weights.
+    // P0 of pass PS, in place: centre and scale the 8 rows (8 lanes per row, one chunk of every column block per lane).
+    // fp32 statistics: the mean from the row sum, the variance from the squares of (x - mean_h) with mean_h the mean
+    // rounded to fp16 (the differences are then exact to fp16 relative precision, whatever the mean) corrected by
+    // (mean - mean_h)^2; the result x * rstd - mean * rstd is formed in fp32 and rounded once.  gamma / beta live in
+    // the weights.
     template <int PS>
     __device__ __forceinline__ void p0_pass() {
-        const int sub = lane & 7, r = 8 * PS + (lane >> 3);
-        const int row = wave * 48 + r;
-        lchar* base = lds + row * RB + ((sub ^ swz(row)) << 4);        // chunk (sub + 8j) ^ sw = 8j + (sub ^ sw)
-        f16x8 v[CPL];
+        lchar* base = lds + (wave * 6 + PS) * RBB + lane * 16;
+        f16x8 v[NCB];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) v[j] = *(const lf16x8*)(base + 128 * j);
+        for (int j = 0; j < NCB; ++j) v[j] = *(const lf16x8*)(base + 1024 * j);
         const f16x2 ones = (f16x2){(f16)1.f, (f16)1.f};
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
+        for (int j = 0; j < NCB; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum = __builtin_amdgcn_fdot2((f16x2){v[j][2 * e], v[j][2 * e + 1]}, ones, sum, false);
         sum = dpp_add8(sum);
@@ -312,7 +335,7 @@ struct K7B {
         const f16x2 nm = (f16x2){(f16)-mh, (f16)-mh};
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
+        for (int j = 0; j < NCB; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const f16x2 d = (f16x2){v[j][2 * e], v[j][2 * e + 1]} + nm;
@@ -323,19 +346,18 @@ struct K7B {
         const float rstd = rsqrtf(var + p.eps);
         const float nmr = -mean * rstd;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
+        for (int j = 0; j < NCB; ++j) {
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (f16)fmaf((float)v[j][e], rstd, nmr);
-            *(lf16x8*)(base + 128 * j) = o;
+            *(lf16x8*)(base + 1024 * j) = o;
         }
     }
 
-    // row-image fragment: row 16*i + n16 of the wave's group, chunk (4*ks + q4) ^ swz(row).  swz(row) = (row >> 1) & 7 does
-    // not depend on i (16*i and 48*wave are multiples of 16) and only touches the low 3 bits of the chunk, so the address
-    // is xb[ks & 1] + a constant
+    // row-image fragment: row 16*i + n16 of the wave's group, chunk 4*ks + q4: row block 2i + (n16 >> 3), column block
+    // ks >> 1, position (4*(ks & 1) + q4) ^ (n16 & 7): xb[ks & 1] + a constant
     __device__ __forceinline__ f16x8 xfrag(int i, int ks) const {
-        return *(const lf16x8*)(lds + xb[ks & 1] + (16 * i * RB + 128 * (ks >> 1)));
+        return *(const lf16x8*)(lds + xb[ks & 1] + (2 * i * RBB + 1024 * (ks >> 1)));
     }
     __device__ __forceinline__ f16x8 wfrag(int unit, int tile) const {
         return *(const lf16x8*)(lds + woffb + ((unit % NU) * UB + tile * 1024));
@@ -436,29 +458,26 @@ struct K7B {
                 }
     }
     // Scores of query tile QT: S^T = K Q^T (query on the lane), softmax over the keys -> P^T as fp16.  Runs inside the
-    // head's v steps, beside their MFMAs.
+    // head's v steps, beside their MFMAs: straight-line code (a branch would cut the step into scheduling regions) —
+    // key tiles that share no pixel with the query tile are computed and masked like any other key.
     template <int QT>
     __device__ __forceinline__ void attn_scores(State& st) {
         f32x4 sc[3];
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if ((need >> (3 * QT + kt)) & 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(st.kh[kt][j], st.qh[QT][j], sc[kt], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j)
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(st.kh[kt][j], st.qh[QT][j], sc[kt], 0, 0, 0);
         }
-        float mx = -1.0e30f;
-        bool ok[3][4];
         const int qp = opaque(qpix[QT]);      // (recomputed per head: 36 compare masks kept across the heads do not fit the SGPRs)
+        float mx = -1.0e30f;
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool pure = (need >> (9 + 3 * QT + kt)) & 1;       // wave-uniform
-                ok[kt][e] = pure || (((need >> (3 * QT + kt)) & 1) && kpix[kt][e] == qp);
-                mx = fmaxf(mx, ok[kt][e] ? sc[kt][e] : -1.0e30f);
+                sc[kt][e] = kpix[kt][e] == qp ? sc[kt][e] : -1.0e30f;      // keys of other pixels: exp2 below gives exactly 0
+                mx = fmaxf(mx, sc[kt][e]);
             }
         mx = quad_max(mx);
         float rs = 0.f;
@@ -466,7 +485,7 @@ struct K7B {
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sc[kt][e] = ok[kt][e] ? __builtin_amdgcn_exp2f(sc[kt][e] - mx) : 0.f;     // (the scale is in W_q)
+                sc[kt][e] = __builtin_amdgcn_exp2f(sc[kt][e] - mx);         // (the scale is in W_q)
                 rs += sc[kt][e];
             }
         rs = quad_sum(rs);
@@ -493,11 +512,10 @@ struct K7B {
             for (int kk = 0; kk < 2; ++kk) {
                 f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt)
-                    if ((need >> (3 * qt + kt)) & 1) {
-                        o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[kt][2 * kk], st.pt[qt][kt], o0, 0, 0, 0);
-                        o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[kt][2 * kk + 1], st.pt[qt][kt], o1, 0, 0, 0);
-                    }
+                for (int kt = 0; kt < 3; ++kt) {
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[kt][2 * kk], st.pt[qt][kt], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[kt][2 * kk + 1], st.pt[qt][kt], o1, 0, 0, 0);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     st.oh[HS][qt][kk][e] = (f16)o0[e];
@@ -523,7 +541,7 @@ struct K7B {
 #pragma unroll
         for (int j = 0; j < nt_of(C); ++j) st.bv[j] = *(const gf32x4*)((const __attribute__((address_space(1))) float*)p.bo2 + o + 32 * (j / 2) + 4 * (j % 2));
     }
-    // residual rows of column group C: requested at the top of the group's last K step, consumed after it
+    // residual rows of column group C: requested at the top of the group's second K step (HBM latency), consumed after it
     template <int C>
     __device__ __forceinline__ void load_residual(State& st) {
 #pragma unroll
@@ -533,7 +551,9 @@ struct K7B {
             for (int a = 0; a < nt_of(C) / 2; ++a) st.rv[i][a] = *(const gf16x8*)(src + C * 128 + 32 * a);
         }
     }
-    // tile pair (2a, 2a+1) gives this lane 8 consecutive columns 32a + 8*q4 .. +7 of row n16 (+16i)
+    // tile pair (2a, 2a+1) gives this lane 8 consecutive columns 32a + 8*q4 .. +7 of row n16 (+16i).  The projection
+    // (bias included: it was the initial accumulator) is rounded to fp16 and the residual added in fp16 — the
+    // reference's order (to_out returns fp16, `attn_output + hidden_states` is an fp16 add).
     template <int C>
     __device__ __forceinline__ void epilogue(State& st) {
 #pragma unroll
@@ -543,9 +563,10 @@ struct K7B {
                 f16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (f16)(st.acc[i][2 * a][e] + (float)st.rv[i][a][e]);
-                    o[4 + e] = (f16)(st.acc[i][2 * a + 1][e] + (float)st.rv[i][a][4 + e]);
+                    o[e] = (f16)st.acc[i][2 * a][e];
+                    o[4 + e] = (f16)st.acc[i][2 * a + 1][e];
                 }
+                o = o + st.rv[i][a];
                 *(gf16x8*)(st.outp[i] + C * 128 + 32 * a) = o;
             }
     }
@@ -566,18 +587,24 @@ struct K7B {
         mma_half<S, 0, nds(S), 0>(st, st.fa);
         // the units of step S+1 have landed for everyone, and nobody reads the units of step S any more
         __builtin_amdgcn_sched_barrier(0);
+        K7B_T(4 * kd + 0)
         wait_vm<inflight(S)>();
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): my reads of step S's units are done (builtin: the
         asm volatile("" ::: "memory");           // compiler then knows st.fb is valid)
         wg_barrier();
+        K7B_T(4 * kd + 1)
         issue_range<hm(S - 1), hm(S)>();
         if constexpr (xp(S) > 0) issue_rows<S - P1S>(gin);
         read_half<S + 1, 0>(st.fa);
         mma_half<S, 1, nds(S + 1), 2 * (hm(S) - hm(S - 1)) + xp(S)>(st, st.fb);
         __builtin_amdgcn_sched_barrier(0);
+        K7B_T(4 * kd + 2)
         if constexpr (kd == 0 && S % HSTEPS == KM - 1) attn_cvt_qk(st);
         if constexpr (kd == 1 && S % HSTEPS == HSTEPS - 1) attn_pv<S / HSTEPS>(st);
         if constexpr (n_st(S) > 0) epilogue<(S - P1S) / HEADS>(st);
+#ifdef K7B_STAMPS
+        if constexpr ((kd == 0 && S % HSTEPS == KM - 1) || (kd == 1 && S % HSTEPS == HSTEPS - 1) || n_st(S) > 0) { asm volatile("" ::"v"(st.oh[0][0][0]), "v"(st.qh[0][0]), "v"(st.kh[2][3])); K7B_T(4 * kd + 3) }
+#endif
     }
     template <int... S>
     __device__ __forceinline__ void steps(State& st, std::integer_sequence<int, S...>) {
@@ -595,9 +622,9 @@ struct K7B {
         q4 = lane >> 4;
         const int g = (0x1320 >> (4 * (n16 >> 2))) & 3;          // g = [0, 2, 3, 1][n >> 2]
         woffb = XB + n16 * 64 + ((q4 ^ g) << 4);
-        const int row = wave * 48 + n16, sw = swz(row);
-        xb[0] = row * RB + ((q4 ^ sw) << 4);
-        xb[1] = row * RB + (((4 + q4) ^ sw) << 4);
+        const int rr = n16 & 7, xrow = (wave * 6 + (n16 >> 3)) * RBB + rr * 128;
+        xb[0] = xrow + ((q4 ^ rr) << 4);
+        xb[1] = xrow + (((4 + q4) ^ rr) << 4);
         // pixel of my query rows / key rows inside the 48-row group (for the block-diagonal mask)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -638,6 +665,11 @@ struct K7B {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wg_barrier();
         read_half<0, 0>(st.fa);
+#ifdef K7B_STAMPS
+        for (int i = 0; i < 16; ++i) tsum[i] = 0;
+        tlast = __builtin_amdgcn_s_memtime();
+        const unsigned long long tstart = tlast;
+#endif
 
         for (;;) {
             // Everything below is straight-line code per tile.  The lane constants are made opaque once per tile: the
@@ -664,6 +696,11 @@ struct K7B {
             tile = next;
             gi = gin;
         }
+#ifdef K7B_STAMPS
+        tsum[12] = __builtin_amdgcn_s_memtime() - tstart;
+        if (lane == 0 && wave == 0 && blockIdx.x < 1024)
+            for (int i = 0; i < 16; ++i) g_k7b_stamps[blockIdx.x * 16 + i] = tsum[i];
+#endif
         wait_vm<0>();        // (the stream ran on into a tile that does not exist: let its copies land before the LDS is released)
     }
 };
