@@ -123,7 +123,9 @@ extern "C" int vdx_debug_read_k7b_stamps(void* dst) {
 #define K7B_T(idx)
 #endif
 
-template <int INNER>
+// F4: F is a multiple of 4 — the 4 key rows a lane holds of a score tile (rows 16*kt + 4*q4 + e) then belong to ONE pixel, so
+// the block-diagonal mask needs one compare per key tile instead of four (F = 24, 16, 12, 8, 4, 48; the others: F4 = false).
+template <int INNER, bool F4>
 struct K7B {
     static constexpr int KS = INNER / 32;                 // MFMA k steps over the model width
     static constexpr int HEADS = INNER / 64;
@@ -147,7 +149,7 @@ struct K7B {
     static constexpr int NCB = INNER / 64;                // column blocks of 64 channels (= PPP: one DMA piece each)
     static constexpr int RBB = NCB * 1024;                // bytes of one row block (8 rows)
     static_assert(PPP == NCB && XB == 24 * RBB, "a DMA piece is one (row block, column block): 8 rows x 128 bytes");
-    static_assert(NCG == 3 && NPS <= HEADS + 1, "the next tile's rows are fetched behind the first column groups and normalised behind the later ones");
+    static_assert(NCG == 3 && NPS == 6 && HEADS == 5, "the row prefetch schedule below is written for three column groups of five steps");
 
     // ---- the static schedule of a tile: step s consumes units [ub(s), ub(s+1)) of the weight stream; the stream runs
     // on into the next tile (s >= NSTEP: the same schedule again)
@@ -171,14 +173,15 @@ struct K7B {
     // issue point come, in this order: the row pieces of the next tile issued there, the stores of a column group's
     // epilogue (end of step s-1), and the loads at the top of step s (q bias of the next head, output bias of the next
     // column group, residual rows).  All of them are unconditional and opaque to the optimiser (see opaque()).
-    static constexpr int xp(int s) { return s >= P1S && s < P1S + NPS ? PPP : 0; }                 // row pieces issued in step s
-    // pass ps is normalised at least five steps after its pieces were issued (the step waits in between retire every
-    // older DMA), and never in the last step of a column group (the epilogue follows)
-    static constexpr int p0_pass_of(int s) {
-        const int v = s - P1S - HEADS;              // steps into the second column group
-        if (v < 0 || v % HEADS == HEADS - 1) return -1;
-        const int ps = v - v / HEADS;
-        return ps < NPS ? ps : -1;
+    // The next tile's rows are requested right AFTER the first column group's epilogue and have landed before the
+    // second one's: an epilogue consumes plain loads, in front of which hipcc waits vmcnt(0) — every DMA in flight at
+    // that point, HBM-latency row pieces included, would be waited for.  Passes 0-2 in step RS0, passes 3-5 in RS0 + 1.
+    static constexpr int RS0 = P1S + HEADS;
+    static constexpr int xp(int s) { return s == RS0 || s == RS0 + 1 ? 3 * PPP : 0; }               // row pieces issued in step s
+    // P0 passes normalised in the first half of step s: bit ps of the result.  Each at least two step waits after its
+    // pieces were issued (the waits retire every older DMA), none in the last step of the second column group.
+    static constexpr int p0_mask_of(int s) {
+        return s == RS0 + 3 ? 0x03 : s == RS0 + 5 ? 0x04 : s == RS0 + 6 ? 0x08 : s == RS0 + 7 ? 0x10 : s == RS0 + 8 ? 0x20 : 0;
     }
     static constexpr int nt_of(int c) { return c < NCGF ? 8 : 4; }
     static constexpr int first_of(int c) { return P1S + c * HEADS; }
@@ -225,7 +228,7 @@ struct K7B {
     int lane, n16, q4, wave, rot;
     int woffb, xb[2];                            // LDS byte addresses: weight fragment base, row-image fragment bases (k step parity)
     int gi, gin;                                 // this wave's row group in this tile / the next tile
-    int qpix[3], kpix[3][4], need;
+    int qpix[3], kpix[3][F4 ? 1 : 4];
 #ifdef K7B_STAMPS
     unsigned long long tsum[16], tlast;
 #endif
@@ -265,6 +268,9 @@ struct K7B {
     }
     template <int U>
     __device__ __forceinline__ void issue_unit() {
+#ifdef K7B_ABL_NOWDMA      /* diagnostic builds (timing only, wrong results): what each part of the tile costs */
+        return;
+#endif
         const char* src = unit_src<U>() + (2 * wave) * 1024 + lane * 16;
         char* dst = smem + XB + (U % NU) * UB + (2 * wave) * 1024;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
@@ -299,6 +305,9 @@ struct K7B {
     // read the zero page (their values must stay finite: a masked key still multiplies a zero probability).
     template <int PS>
     __device__ __forceinline__ void issue_rows(int g4) {
+#ifdef K7B_ABL_NOROWS
+        return;
+#endif
         const int r = 8 * PS + (lane >> 3);
         long long gr;
         const bool ok = grow_of(g4, r, gr);
@@ -318,6 +327,9 @@ struct K7B {
     // the weights.
     template <int PS>
     __device__ __forceinline__ void p0_pass() {
+#ifdef K7B_ABL_NOROWS
+        return;
+#endif
         lchar* base = lds + (wave * 6 + PS) * RBB + lane * 16;
         f16x8 v[NCB];
 #pragma unroll
@@ -462,6 +474,10 @@ struct K7B {
     // key tiles that share no pixel with the query tile are computed and masked like any other key.
     template <int QT>
     __device__ __forceinline__ void attn_scores(State& st) {
+#ifdef K7B_ABL_NOATT
+        for (int kt = 0; kt < 3; ++kt) st.pt[QT][kt] = st.qh[QT][kt] + st.kh[kt][QT];
+        return;
+#endif
         f32x4 sc[3];
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
@@ -476,7 +492,7 @@ struct K7B {
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sc[kt][e] = kpix[kt][e] == qp ? sc[kt][e] : -1.0e30f;      // keys of other pixels: exp2 below gives exactly 0
+                sc[kt][e] = kpix[kt][F4 ? 0 : e] == qp ? sc[kt][e] : -1.0e30f;      // keys of other pixels: exp2 below gives exactly 0
                 mx = fmaxf(mx, sc[kt][e]);
             }
         mx = quad_max(mx);
@@ -499,6 +515,12 @@ struct K7B {
     // by side are one B operand of the output projection (k index of W_o permuted to match: packing.pack_k7b).
     template <int HS>
     __device__ __forceinline__ void attn_pv(State& st) {
+#ifdef K7B_ABL_NOATT
+        for (int qt = 0; qt < 3; ++qt)
+            for (int kk = 0; kk < 2; ++kk)
+                for (int e = 0; e < 8; ++e) st.oh[HS][qt][kk][e] = (f16)st.av[qt][2 * kk + (e >> 2)][e & 3] + st.pt[qt][kk][e & 3];
+        return;
+#endif
         f16x4 vh[3][4];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -544,6 +566,10 @@ struct K7B {
     // residual rows of column group C: requested at the top of the group's second K step (HBM latency), consumed after it
     template <int C>
     __device__ __forceinline__ void load_residual(State& st) {
+#ifdef K7B_ABL_NOEPI
+        for (int i = 0; i < 3; ++i) for (int a = 0; a < 4; ++a) st.rv[i][a] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const gf16* src = st.resp[i] + opaque(0);
@@ -556,6 +582,10 @@ struct K7B {
     // reference's order (to_out returns fp16, `attn_output + hidden_states` is an fp16 add).
     template <int C>
     __device__ __forceinline__ void epilogue(State& st) {
+#ifdef K7B_ABL_NOEPI
+        for (int a = 0; a < nt_of(C); ++a) for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(st.acc[i][a]));
+        return;
+#endif
 #pragma unroll
         for (int a = 0; a < nt_of(C) / 2; ++a)
 #pragma unroll
@@ -581,7 +611,7 @@ struct K7B {
         if constexpr (n_res(S) > 0) load_residual<(S - P1S) / HEADS>(st);
         // vector work that rides on this step's MFMAs: the scores of the head (v steps 0..2), the next tile's rows
         if constexpr (kd == 1 && S % HSTEPS - KM < 3) attn_scores<S % HSTEPS - KM>(st);
-        if constexpr (p0_pass_of(S) >= 0) p0_pass<p0_pass_of(S)>();
+        p0_passes<p0_mask_of(S)>(std::make_integer_sequence<int, NPS>{});
         // second half's fragments behind the first half's MFMAs
         read_half<S, 1>(st.fb);
         mma_half<S, 0, nds(S), 0>(st, st.fa);
@@ -594,7 +624,11 @@ struct K7B {
         wg_barrier();
         K7B_T(4 * kd + 1)
         issue_range<hm(S - 1), hm(S)>();
-        if constexpr (xp(S) > 0) issue_rows<S - P1S>(gin);
+        if constexpr (xp(S) > 0) {
+            issue_rows<3 * (S - RS0)>(gin);
+            issue_rows<3 * (S - RS0) + 1>(gin);
+            issue_rows<3 * (S - RS0) + 2>(gin);
+        }
         read_half<S + 1, 0>(st.fa);
         mma_half<S, 1, nds(S + 1), 2 * (hm(S) - hm(S - 1)) + xp(S)>(st, st.fb);
         __builtin_amdgcn_sched_barrier(0);
@@ -609,6 +643,10 @@ struct K7B {
     template <int... S>
     __device__ __forceinline__ void steps(State& st, std::integer_sequence<int, S...>) {
         (step<S>(st), ...);
+    }
+    template <int MASK, int... PS>
+    __device__ __forceinline__ void p0_passes(std::integer_sequence<int, PS...>) {
+        ((MASK >> PS & 1 ? p0_pass<PS>() : void()), ...);
     }
     template <int... PS>
     __device__ __forceinline__ void first_rows(std::integer_sequence<int, PS...>) {
@@ -630,7 +668,7 @@ struct K7B {
         for (int i = 0; i < 3; ++i) {
             qpix[i] = ((16 * i + n16) * p.fmagic) >> 16;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) kpix[i][e] = ((16 * i + 4 * q4 + e) * p.fmagic) >> 16;
+            for (int e = 0; e < (F4 ? 1 : 4); ++e) kpix[i][e] = ((16 * i + 4 * q4 + e) * p.fmagic) >> 16;
         }
     }
 
@@ -640,20 +678,6 @@ struct K7B {
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         rot = (blockIdx.x >> 3) % HEADS;                        // blocks b and b+8 share an XCD (see tattn_fused.hip)
         set_lane_constants();
-        // 16-row tiles of the group that share no pixel need no score tile at all (F = 16: only the diagonal; F = 24:
-        // 7 of 9): bit 3*qt + kt of `need` says query tile qt has a pixel in common with key tile kt (wave-uniform);
-        // bit 9 + 3*qt + kt: both tiles lie inside ONE pixel, no mask
-        need = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int alo = 16 * a / p.F, ahi = (16 * a + 15) / p.F, blo = 16 * b / p.F, bhi = (16 * b + 15) / p.F;
-                if (!(ahi < blo || bhi < alo)) need |= 1 << (3 * a + b);
-                if (alo == ahi && blo == bhi && alo == blo) need |= 1 << (9 + 3 * a + b);
-            }
-        need = __builtin_amdgcn_readfirstlane(need);
-
         // ---- first tile: the weight stream, the tile's rows, the first q bias; everything has landed before the first
         // step (so its counted wait finds nothing outstanding), the rows are centred and scaled in place
         int tile = blockIdx.x;
@@ -705,10 +729,10 @@ struct K7B {
     }
 };
 
-template <int INNER>
+template <int INNER, bool F4>
 __global__ __launch_bounds__(256, 1) void tattn2_kernel(const K7BP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    K7B<INNER> k(p, smem);
+    K7B<INNER, F4> k(p, smem);
     k.run();
 }
 
@@ -720,7 +744,7 @@ extern "C" int vdx_temporal_attn_block2_supported(int inner, int F) {
 // bytes of the packed blob (vdx/packing.py pack_k7b): q|k|v units, output-projection units, fp32 q bias, fp32 output bias
 extern "C" size_t vdx_temporal_attn_block2_pack_bytes(int inner) {
     if (inner != 320) return 0;
-    return (size_t)K7B<320>::NUNITS * K7B<320>::UB + 2 * 320 * sizeof(float);
+    return (size_t)K7B<320, true>::NUNITS * K7B<320, true>::UB + 2 * 320 * sizeof(float);
 }
 
 extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* packed, float eps, void* out, int ldo,
@@ -731,7 +755,7 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     VDX_CHECK(ldt % 8 == 0 && ldo % 8 == 0 && ldt >= inner && ldo >= inner, "temporal_attn_block2: bad leading dims");
     VDX_CHECK((long long)B * F * HW < (1ll << 31), "temporal_attn_block2: too many rows");
     VDX_CHECK(((uintptr_t)t % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)packed % 16 == 0), "temporal_attn_block2: pointers must be 16-byte aligned");
-    typedef K7B<320> T;
+    typedef K7B<320, true> T;
     K7BP p;
     p.t = (const f16*)t; p.out = (f16*)out;
     p.wqkv = (const char*)packed;
@@ -746,13 +770,17 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     p.fmagic = (65536 + F - 1) / F;
     p.eps = eps;
     constexpr int lds = T::XB + T::NU * T::UB;
-    auto kern = tattn2_kernel<320>;
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static const hipError_t attr_rc = [] {
+        hipError_t a = hipFuncSetAttribute((const void*)tattn2_kernel<320, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t b = hipFuncSetAttribute((const void*)tattn2_kernel<320, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        return a != hipSuccess ? a : b;
+    }();
     if (attr_rc != hipSuccess) return vdx_fail("temporal_attn_block2: cannot reserve %d bytes of LDS", lds);
     // persistent grid: every workgroup walks the same number of tiles (+-1), one workgroup per CU at most
     const int ncu = vdx_num_cus();
     const int rounds = (p.ntiles + ncu - 1) / ncu;
     const int grid = (p.ntiles + rounds - 1) / rounds;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    if (F % 4 == 0) hipLaunchKernelGGL((tattn2_kernel<320, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((tattn2_kernel<320, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return vdx_launch_status("vdx_temporal_attn_block2_f16");
 }

@@ -22,3 +22,10 @@ for inner in (320, 512):
     for _ in range(4):
         ops.temporal_attn_block(t, g, b_, pq, po, bo, B=B, F=F, HW=HW, scale=0.125, out=out)
     torch.cuda.synchronize()
+    if inner in packing.K7B_WIDTHS:        # the second design (csrc/tattn2.hip), F = 24 and 16
+        blob = packing.pack_k7b(*w, g, b_, bo, 0.125).contiguous()
+        for F2 in (24, 16):
+            M2 = B * F2 * HW
+            for _ in range(4):
+                ops.temporal_attn_block2(t[:M2], blob, B=B, F=F2, HW=HW, out=out[:M2])
+        torch.cuda.synchronize()

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dev tool: wall time of the second fused temporal-attention kernel alone (library from VDX_LIB_PATH: the product or a
+-DK7B_ABL_* timing-only build), level-0 shape, F = 24 and 16, median of 9."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vdx  # noqa: E402,F401
+from vdx import ops, packing  # noqa: E402
+
+dev = torch.device("cuda:0")
+res = []
+inner = 320
+for F in (24, 16):
+    B, HW = 2, 72 * 128
+    M = B * F * HW
+    t = torch.randn(M, inner, device=dev).half()
+    v = lambda s=0.1: (torch.randn(inner, device=dev) * s).half()   # noqa: E731
+    w = [(torch.randn(inner, inner, device=dev) * 0.06).half() for _ in range(4)]
+    blob = packing.pack_k7b(*w, v() + 1, v(), v(), 0.125).contiguous()
+    out = torch.empty_like(t)
+    ts = []
+    for i in range(12):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.temporal_attn_block2(t, blob, B=B, F=F, HW=HW, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            ts.append(e0.elapsed_time(e1))
+    res.append(f"F {F}: {sorted(ts)[len(ts) // 2]:.3f} ms")
+print(os.path.basename(os.environ.get("VDX_LIB_PATH", "libvdx_hip.so")), " | ".join(res))
