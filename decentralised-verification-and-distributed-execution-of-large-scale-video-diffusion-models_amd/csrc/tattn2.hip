@@ -59,8 +59,8 @@ struct K7BP {
     int B, F, S;         // batch items, frames per pixel, pixels per frame
     int G;               // pixels per row group = 48 / F
     int gpb;             // row groups per batch item = ceil(S / G)
-    int ngroups;         // B * gpb
-    int ntiles;          // ceil(ngroups / 4)
+    int tps;             // tiles per batch item = ceil(gpb / 4): a tile never straddles two batch items
+    int ntiles;          // B * tps
     int fmagic;          // ceil(65536 / F): row / F == (row * fmagic) >> 16 for row < 64
     float eps;
 };
@@ -110,13 +110,20 @@ static __device__ unsigned long long g_k7b_stamps[1024 * 16];
 extern "C" int vdx_debug_read_k7b_stamps(void* dst) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_k7b_stamps), sizeof(g_k7b_stamps)) == hipSuccess ? 0 : -1;
 }
+#ifndef K7B_SS
+#define K7B_SS 0
+#define K7B_SE 1000
+#define K7B_IDX(idx) (idx)
+#else
+#define K7B_IDX(idx) ((idx) % 4)           /* one range of steps: the four segments only */
+#endif
 #define K7B_T(idx)                                                                                     \
-    {                                                                                                  \
+    if constexpr ((S >= K7B_SS && S <= K7B_SE) || S == (K7B_SS + 64) % 65) {                            \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         unsigned long long now_;                                                                       \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                    \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        tsum[idx] += now_ - tlast;                                                                     \
+        if constexpr (S >= K7B_SS && S <= K7B_SE) tsum[K7B_IDX(idx)] += now_ - tlast;                   \
         tlast = now_;                                                                                  \
     }
 #else
@@ -225,9 +232,15 @@ struct K7B {
     const K7BP& p;
     char* smem;
     lchar* lds;                                  // the same, as an LDS pointer
-    int lane, n16, q4, wave, rot;
+    int lane, n16, q4, wave;
+    // order in which this tile / the next tile walks the heads: rotated by the tile's position INSIDE its batch item.
+    // Why rotate at all: see tattn_fused.hip (workgroups that share an XCD would otherwise ask for the same weight lines at
+    // the same time and then not again for a whole tile).  Why by that position: the output projection sums the heads in
+    // walking order, so the order must be a function of the data alone — a sample's result then has the same bits
+    // wherever it sits in the batch, whatever the grid (tests/test_unet_gpu.py: batch independence).
+    int rot, rotn;
     int woffb, xb[2];                            // LDS byte addresses: weight fragment base, row-image fragment bases (k step parity)
-    int gi, gin;                                 // this wave's row group in this tile / the next tile
+    int tb, tg, tbn, tgn;                        // this wave's (batch item, row group inside it) in this tile / the next tile
     int qpix[3], kpix[3][F4 ? 1 : 4];
 #ifdef K7B_STAMPS
     unsigned long long tsum[16], tlast;
@@ -246,21 +259,22 @@ struct K7B {
     template <int U>
     __device__ __forceinline__ const char* unit_src() const {
         constexpr int u = U % NUNITS;
+        const int r = U >= NUNITS ? rotn : rot;          // (the stream runs on into the next tile)
         if constexpr (u < UPH * HEADS) {
             constexpr int hs = u / UPH, w = u % UPH;
-            int h = hs + rot;
+            int h = hs + r;
             if (h >= HEADS) h -= HEADS;
             return p.wqkv + (size_t)(h * UPH + w) * UB;
         } else {
             constexpr int v = u - UPH * HEADS;
             if constexpr (v < 2 * HEADS * NCGF) {
-                constexpr int cg = v / (2 * HEADS), r = v % (2 * HEADS), hs = r / 2, kk = r % 2;
-                int h = hs + rot;
+                constexpr int cg = v / (2 * HEADS), rr = v % (2 * HEADS), hs = rr / 2, kk = rr % 2;
+                int h = hs + r;
                 if (h >= HEADS) h -= HEADS;
                 return p.wo + (size_t)(cg * 2 * HEADS + h * 2 + kk) * UB;
             } else {
                 constexpr int hs = v - 2 * HEADS * NCGF;
-                int h = hs + rot;
+                int h = hs + r;
                 if (h >= HEADS) h -= HEADS;
                 return p.wo + (size_t)(2 * HEADS * NCGF + h) * UB;
             }
@@ -284,12 +298,12 @@ struct K7B {
         }
     }
 
-    // global row index of local row r (0..47) of row group g4 (clamped to row 0 when it does not exist) and whether it
-    // exists; branch-free: every lane computes an address, the caller selects
-    __device__ __forceinline__ bool grow_of(int g4, int r, long long& gr) const {
+    // global row index of local row r (0..47) of row group g4 of batch item b (clamped to row 0 when it does not exist)
+    // and whether it exists; branch-free: every lane computes an address, the caller selects
+    __device__ __forceinline__ bool grow_of(int b, int g4, int r, long long& gr) const {
         const int g = (r * p.fmagic) >> 16, f = r - g * p.F;
-        const int b = g4 / p.gpb, pix = (g4 - b * p.gpb) * p.G + g;            // (g4 is wave-uniform: scalar division)
-        const bool ok = g4 < p.ngroups && pix < p.S;
+        const int pix = g4 * p.G + g;
+        const bool ok = b < p.B && g4 < p.gpb && pix < p.S;
         gr = ok ? (long long)((b * p.F + f) * p.S + pix) : 0ll;
         return ok;
     }
@@ -304,13 +318,13 @@ struct K7B {
     // rows of row group g4, pass PS (its 8 rows) -> the wave's part of the image, by LDS-DMA.  Rows that do not exist
     // read the zero page (their values must stay finite: a masked key still multiplies a zero probability).
     template <int PS>
-    __device__ __forceinline__ void issue_rows(int g4) {
+    __device__ __forceinline__ void issue_rows(int b, int g4) {
 #ifdef K7B_ABL_NOROWS
         return;
 #endif
         const int r = 8 * PS + (lane >> 3);
         long long gr;
-        const bool ok = grow_of(g4, r, gr);
+        const bool ok = grow_of(b, g4, r, gr);
         const char* rowp = (const char*)(p.t + gr * p.ldt) + (((lane & 7) ^ (lane >> 3)) << 4);
         const char* zp = (const char*)g_zero_page;
         const char* src = ok ? rowp : zp;
@@ -547,9 +561,9 @@ struct K7B {
     }
 
     // q bias of the head in time slot HS: the initial accumulator of its q (d = 16*j + 4*q4 + e on the registers)
-    template <int HS>
+    template <int HS, bool NEXT_TILE = false>
     __device__ __forceinline__ void load_bq(State& st) {
-        int h = HS + rot;
+        int h = HS + (NEXT_TILE ? rotn : rot);
         if (h >= HEADS) h -= HEADS;
         const int o = opaque(h * 64 + 4 * q4);
 #pragma unroll
@@ -606,7 +620,7 @@ struct K7B {
     __device__ __forceinline__ void step(State& st) {
         constexpr int kd = kind(S);
         // loads of later steps, requested here (counted by younger(S))
-        if constexpr (n_bq(S) > 0) load_bq<(S == NSTEP - 1 ? 0 : S / HSTEPS + 1)>(st);
+        if constexpr (n_bq(S) > 0) load_bq<(S == NSTEP - 1 ? 0 : S / HSTEPS + 1), S == NSTEP - 1>(st);
         if constexpr (n_bias(S) > 0) load_bias<(S + 1 - P1S) / HEADS>(st);
         if constexpr (n_res(S) > 0) load_residual<(S - P1S) / HEADS>(st);
         // vector work that rides on this step's MFMAs: the scores of the head (v steps 0..2), the next tile's rows
@@ -625,9 +639,9 @@ struct K7B {
         K7B_T(4 * kd + 1)
         issue_range<hm(S - 1), hm(S)>();
         if constexpr (xp(S) > 0) {
-            issue_rows<3 * (S - RS0)>(gin);
-            issue_rows<3 * (S - RS0) + 1>(gin);
-            issue_rows<3 * (S - RS0) + 2>(gin);
+            issue_rows<3 * (S - RS0)>(tbn, tgn);
+            issue_rows<3 * (S - RS0) + 1>(tbn, tgn);
+            issue_rows<3 * (S - RS0) + 2>(tbn, tgn);
         }
         read_half<S + 1, 0>(st.fa);
         mma_half<S, 1, nds(S + 1), 2 * (hm(S) - hm(S - 1)) + xp(S)>(st, st.fb);
@@ -650,7 +664,7 @@ struct K7B {
     }
     template <int... PS>
     __device__ __forceinline__ void first_rows(std::integer_sequence<int, PS...>) {
-        (issue_rows<PS>(gi), ...);
+        (issue_rows<PS>(tb, tg), ...);
         wait_vm<0>();
         (p0_pass<PS>(), ...);
     }
@@ -672,18 +686,27 @@ struct K7B {
         }
     }
 
+    // tile -> (batch item, this wave's row group inside it, head rotation); tiles are aligned to batch items
+    __device__ __forceinline__ void set_tile(int tile, int& b, int& g4, int& r) const {
+        b = tile / p.tps;
+        const int tt = tile - b * p.tps;
+        g4 = tt * 4 + wave;
+        r = tt % HEADS;
+    }
+
     __device__ __forceinline__ void run() {
         const int tid = threadIdx.x;
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        rot = (blockIdx.x >> 3) % HEADS;                        // blocks b and b+8 share an XCD (see tattn_fused.hip)
         set_lane_constants();
+
         // ---- first tile: the weight stream, the tile's rows, the first q bias; everything has landed before the first
         // step (so its counted wait finds nothing outstanding), the rows are centred and scaled in place
         int tile = blockIdx.x;
-        gi = tile * 4 + wave;
+        set_tile(tile, tb, tg, rot);
+        rotn = rot;
         State st;
-        issue_range<0, hm(-1)>();
+        issue_range<0, NU>();
         load_bq<0>(st);
         first_rows(std::make_integer_sequence<int, NPS>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -700,15 +723,15 @@ struct K7B {
             // optimiser otherwise hoists every address that depends only on them (hundreds) out of this loop and
             // spills them around it.
             asm volatile("" : "+v"(lane));
-            asm volatile("" : "+s"(wave), "+s"(rot));
+            asm volatile("" : "+s"(wave));
             set_lane_constants();
             const int next = tile + gridDim.x;
-            gin = next * 4 + wave;              // (past the last tile: every row reads the zero page)
+            set_tile(next, tbn, tgn, rotn);      // (past the last tile: every row reads the zero page)
             // rows that do not exist (last tile) read and write the dump page: every tile issues the same instructions
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 long long gr;
-                const bool ok = grow_of(gi, 16 * i + n16, gr);
+                const bool ok = grow_of(tb, tg, 16 * i + n16, gr);
                 gf16* dump = (gf16*)g_dump_page + lane * 8;
                 const gf16* rp = (const gf16*)p.t + gr * p.ldt + 8 * q4;
                 gf16* op = (gf16*)p.out + gr * p.ldo + 8 * q4;
@@ -718,7 +741,9 @@ struct K7B {
             steps(st, std::make_integer_sequence<int, NSTEP>{});
             if (next >= p.ntiles) break;
             tile = next;
-            gi = gin;
+            tb = tbn;
+            tg = tgn;
+            rot = rotn;
         }
 #ifdef K7B_STAMPS
         tsum[12] = __builtin_amdgcn_s_memtime() - tstart;
@@ -765,8 +790,8 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     p.ldt = ldt; p.ldo = ldo; p.B = B; p.F = F; p.S = HW;
     p.G = 48 / F;
     p.gpb = (HW + p.G - 1) / p.G;
-    p.ngroups = B * p.gpb;
-    p.ntiles = (p.ngroups + 3) / 4;
+    p.tps = (p.gpb + 3) / 4;
+    p.ntiles = B * p.tps;
     p.fmagic = (65536 + F - 1) / F;
     p.eps = eps;
     constexpr int lds = T::XB + T::NU * T::UB;

@@ -562,6 +562,27 @@ def test_temporal_attn_block2_fused(gpu, B, Fr, HW):
     assert torch.equal(wide_out[:, :inner], out) and bool((wide_out[:, inner:] == 7.0).all())
 
 
+@pytest.mark.parametrize("Fr,HW", [(24, 1100), (16, 37), (12, 700)])
+def test_temporal_attn_block2_batch_invariant(gpu, Fr, HW):
+    """A sample's result has the same bits wherever it sits in the batch and whatever else is in it: tiles are aligned
+    to batch items and the order in which a tile sums the heads is a function of its position inside the item (the
+    persistent grid, the block that happens to own a tile and the batch size do not enter)."""
+    ops, _ = _ops()
+    from vdx import packing
+    inner = 320
+    g = torch.Generator().manual_seed(Fr + HW)
+    t1 = h(torch.randn(Fr * HW, inner, generator=g) * 1.5 + 0.3).half()
+    t2 = h(torch.randn(Fr * HW, inner, generator=g)).half()
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    wq, wk, wv, wo = (h(torch.randn(inner, inner, generator=g) * s_) for s_ in (0.09, 0.09, 0.06, 0.05))
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    blob = packing.pack_k7b(wq, wk, wv, wo, gamma, beta, bo, 0.125).to(gpu)
+    alone = ops.temporal_attn_block2(t1.to(gpu), blob, B=1, F=Fr, HW=HW)
+    three = ops.temporal_attn_block2(torch.cat([t2, t1, t1]).to(gpu), blob, B=3, F=Fr, HW=HW)
+    M = Fr * HW
+    assert torch.equal(three[M:2 * M], alone) and torch.equal(three[2 * M:], alone)
+
+
 def test_temporal_attn_block2_large_mean(gpu):
     """Rows whose mean is far from zero (|mean| = 40 sigma): the statistics are two-pass fp32, the centred row is
     formed as x * rstd - mean * rstd in fp32 before the fp16 rounding."""
