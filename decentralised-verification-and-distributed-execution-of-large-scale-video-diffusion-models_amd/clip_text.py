@@ -79,6 +79,8 @@ class CLIPTextModel(nn.Module):
 
         def get(k):
             used.add(k)
+            if k not in sd:
+                raise VdxError(f"missing key in state dict: {k}")
             return sd[k].to(dev)
 
         def put(name, t):

@@ -105,6 +105,61 @@ def _load_file(path_no_ext_candidates):
     return None
 
 
+def _read_json(path):
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def _unet_config(d):
+    """`unet/config.json` (diffusers `UNet3DConditionModel.config`) -> UNet3DConfig; the Zeroscope values where the file
+    or a key is absent.  Refuses what the kernels are not built for instead of loading it wrong."""
+    j = _read_json(f"{d}/unet/config.json")
+    if j is None:
+        return _unet.UNet3DConfig.zeroscope()
+    hd = j.get("attention_head_dim", 64)
+    hd = set(hd) if isinstance(hd, (list, tuple)) else {hd}
+    if hd != {64}:
+        raise ValueError(f"unet/config.json: attention_head_dim {sorted(hd)} — the attention kernels are built for 64")
+    if j.get("num_attention_heads") not in (None, 64) or j.get("act_fn", "silu") != "silu":
+        raise ValueError("unet/config.json: only the ModelScope / Zeroscope UNet3D variant (silu, head dim 64) is implemented")
+    z = _unet.UNet3DConfig.zeroscope()
+    return _unet.UNet3DConfig(
+        in_channels=j.get("in_channels", z.in_channels), out_channels=j.get("out_channels", z.out_channels),
+        block_out_channels=tuple(j.get("block_out_channels", z.block_out_channels)),
+        layers_per_block=j.get("layers_per_block", z.layers_per_block), attention_head_dim=64,
+        cross_attention_dim=j.get("cross_attention_dim", z.cross_attention_dim),
+        norm_num_groups=j.get("norm_num_groups", z.norm_num_groups), norm_eps=j.get("norm_eps", z.norm_eps),
+        transformer_in_heads=z.transformer_in_heads,        # (fixed at 8 in diffusers' UNet3DConditionModel)
+        down_block_types=tuple(j.get("down_block_types", z.down_block_types)),
+        up_block_types=tuple(j.get("up_block_types", z.up_block_types)))
+
+
+def _vae_config(d):
+    j = _read_json(f"{d}/vae/config.json")
+    z = _vae.VaeConfig.sd()
+    if j is None:
+        return z
+    return _vae.VaeConfig(latent_channels=j.get("latent_channels", z.latent_channels), out_channels=j.get("out_channels", z.out_channels),
+                          block_out_channels=tuple(j.get("block_out_channels", z.block_out_channels)),
+                          layers_per_block=j.get("layers_per_block", z.layers_per_block),
+                          norm_num_groups=j.get("norm_num_groups", z.norm_num_groups),
+                          scaling_factor=j.get("scaling_factor", z.scaling_factor))
+
+
+def _clip_config(d):
+    j = _read_json(f"{d}/text_encoder/config.json")
+    z = _clip.CLIPTextConfig.sd2()
+    if j is None:
+        return z
+    if j.get("hidden_act", "gelu") != "gelu":
+        raise ValueError(f"text_encoder/config.json: hidden_act {j.get('hidden_act')!r} — only the OpenCLIP tower of SD-2.x (gelu) is implemented")
+    return _clip.CLIPTextConfig(**{k: j.get(k, getattr(z, k)) for k in (
+        "vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "max_position_embeddings",
+        "layer_norm_eps")})
+
+
 class DiffusionPipeline:
     def __init__(self, unet, text_encoder, vae, tokenizer, scheduler, synthetic):
         self.unet, self.text_encoder, self.vae = unet, text_encoder, vae
@@ -122,6 +177,11 @@ class DiffusionPipeline:
             text = CLIPTextModel(_clip.CLIPTextConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=2,
                                                       num_attention_heads=2))
             vae = AutoencoderKL(_vae.VaeConfig(block_out_channels=(64, 64, 128, 128)))
+        elif os.path.isdir(str(model_id)):      # a checkpoint in diffusers layout: its own config.json files give the widths
+            d = str(model_id)
+            unet = UNet3DConditionModel(_unet_config(d))
+            text = CLIPTextModel(_clip_config(d))
+            vae = AutoencoderKL(_vae_config(d))
         else:
             unet = UNet3DConditionModel(_unet.UNet3DConfig.zeroscope())
             text = CLIPTextModel(_clip.CLIPTextConfig.sd2())

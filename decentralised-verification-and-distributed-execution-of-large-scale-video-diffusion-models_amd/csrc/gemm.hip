@@ -107,13 +107,18 @@ struct Stager {
                 __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)d0[i] * ld), (lptr_t)(sa + i * RPP * 128), 16, 0, 0);
         } else if (MODE == 1) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int hlim = p.h_in << p.ups, wlim = p.w_in << p.ups;
+            const int hlim = p.h_up, wlim = p.w_up;
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
                 int y = (d1[i] >> 16) + ky - 1, x = (d1[i] & 0xffff) + kx - 1;
                 const bool ok = (unsigned)y < (unsigned)hlim && (unsigned)x < (unsigned)wlim;
-                y >>= p.ups;
-                x >>= p.ups;
+                if (p.ups == 1) {
+                    y >>= 1;
+                    x >>= 1;
+                } else if (p.ups == 2) {      // explicit target size (latent not divisible by 8): F.interpolate(size=, "nearest")
+                    y = min((int)((float)y * p.usy), p.h_in - 1);
+                    x = min((int)((float)x * p.usx), p.w_in - 1);
+                }
                 const f16* src = p.a + (size_t)(d0[i] + y * p.w_in + x) * p.lda + kc + csw;
                 __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * RPP * 128), 16, 0, 0);
             }
@@ -352,7 +357,11 @@ static int gemm_prepare(const vdx_gemm_args* a, GemmP& p, bool& geglu, int& forc
     p.M = a->row_end ? a->row_end : a->M; p.m_begin = a->row_begin; p.N = a->N; p.K = a->K; p.c1 = a->c1; p.c2 = a->c2;
     p.lda = a->lda; p.lda2 = a->lda2; p.ldo = a->ldo; p.ldr = a->ldr;
     p.h_in = a->h_in; p.w_in = a->w_in; p.h_out = a->h_out; p.w_out = a->w_out;
-    p.stride = a->stride; p.ups = a->upsample ? 1 : 0;
+    p.stride = a->stride; p.ups = a->upsample;
+    p.h_up = a->upsample == 1 ? 2 * a->h_in : a->upsample == 2 ? a->h_out : a->h_in;
+    p.w_up = a->upsample == 1 ? 2 * a->w_in : a->upsample == 2 ? a->w_out : a->w_in;
+    p.usy = a->h_in > 0 && p.h_up > 0 ? (float)a->h_in / (float)p.h_up : 1.0f;
+    p.usx = a->w_in > 0 && p.w_up > 0 ? (float)a->w_in / (float)p.w_up : 1.0f;
     p.frames = a->frames; p.hw = a->hw; p.rpb2 = a->rows_per_bias2 > 0 ? a->rows_per_bias2 : 1;
     p.ldb2 = a->ldb2 > 0 ? a->ldb2 : a->N;
     VDX_CHECK(p.ldb2 % 8 == 0, "gemm: ldb2 must be a multiple of 8");
@@ -383,7 +392,9 @@ static int gemm_prepare(const vdx_gemm_args* a, GemmP& p, bool& geglu, int& forc
             VDX_CHECK(a->h_in > 0 && a->w_in > 0 && a->h_out > 0 && a->w_out > 0, "gemm: conv geometry");
             VDX_CHECK(a->M % (a->h_out * a->w_out) == 0, "gemm: M=%d not a whole number of %dx%d images", a->M, a->h_out, a->w_out);
             {
-                const int he = a->h_in << p.ups, we = a->w_in << p.ups;
+                VDX_CHECK(a->upsample >= 0 && a->upsample <= 2 && (a->upsample == 0 || a->stride == 1), "gemm: upsample %d with stride %d", a->upsample, a->stride);
+                VDX_CHECK(a->upsample != 2 || (a->h_out >= a->h_in && a->w_out >= a->w_in), "gemm: upsample-to-size target smaller than the source");
+                const int he = p.h_up, we = p.w_up;
                 VDX_CHECK(a->h_out == (he + 2 - 3) / a->stride + 1 && a->w_out == (we + 2 - 3) / a->stride + 1,
                           "gemm: conv output %dx%d inconsistent with input %dx%d stride %d", a->h_out, a->w_out, he, we, a->stride);
             }

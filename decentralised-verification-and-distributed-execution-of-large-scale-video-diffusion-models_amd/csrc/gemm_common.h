@@ -7,7 +7,10 @@ struct GemmP {
     f16* out;
     int M, N, K, c1, c2;
     int lda, lda2, ldo, ldr;
-    int h_in, w_in, h_out, w_out, stride, ups;
+    int h_in, w_in, h_out, w_out, stride;
+    int ups;          // conv3x3 source: 0 as is, 1 nearest x2, 2 nearest to (h_up, w_up) (torch's rule: floor(dst * in / out) in fp32)
+    int h_up, w_up;   // extent of the (virtually) upsampled source
+    float usy, usx;   // ups == 2: in / out as fp32
     int frames, hw, rpb2, ldb2;
     int ntn, ntm;
     int m_begin;      // first row computed (tiles start here)

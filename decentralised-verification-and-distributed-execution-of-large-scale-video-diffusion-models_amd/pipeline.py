@@ -5,14 +5,20 @@ Same configuration names as the reference's argparse (`:281-300`): num_frames, s
 guidance_scale, chunk_size, overlap, height, width, mode {fsdp, chunk, hybrid, hybrid_ctx},
 context_weight.  Differences in mechanism (results identical):
   * the per-step arithmetic (ctx injection, CFG combine, DDIM step) runs as two fused kernels;
-  * denoised chunks stay on the device.  Default exchange ("halo"): every frame of the video has ONE owning
-    rank (the rank of the first window that starts at or before it and whose successor starts after it); a
-    rank sends only the frames of its windows that another rank owns — the `overlap` halo frames, 288 KiB per
-    neighbour at XL size — as fixed-shape point-to-point transfers (RCCL send/recv over xGMI, issued on a side
-    HIP stream with event hand-off) and blends and decodes only the frames it owns.  The per-frame accumulation
-    order is the reference's (`for lst in gathered: for s,e,latc in lst`, :208-216), so the owned frames carry
-    exactly the bits of the reference's full blend.  `exchange="allgather"` keeps the reference's
-    everyone-gets-everything semantics (`all_gather_object`, :201) as one fixed-shape `all_gather`;
+  * denoised chunks stay on the device.  `__call__(exchange="allgather")` — the DEFAULT — keeps the reference's
+    everyone-gets-everything semantics (`all_gather_object`, :201) as one fixed-shape `all_gather` and returns the whole
+    blended latent.  `exchange="halo"` returns a DIFFERENT type — the list of (s, e, latent) segments this rank owns:
+    every frame of the video has ONE owning rank (the rank of the first window that starts at or before it and whose
+    successor starts after it); a rank sends only the frames of its windows that another rank owns — the `overlap`
+    halo frames, 288 KiB per neighbour at XL size — as fixed-shape point-to-point transfers (RCCL send/recv over xGMI,
+    issued on a side HIP stream with event hand-off; `comm=` routes them through the C-ABI entry point
+    `vdx_halo_exchange` instead of torch.distributed) and blends and decodes only the frames it owns.  The per-frame
+    accumulation order is the reference's (`for lst in gathered: for s,e,latc in lst`, :208-216), so the owned frames
+    carry exactly the bits of the reference's full blend.
+    `info["network_bytes"]` = bytes this rank RECEIVES in the exchange (allgather: (world-1) fixed-shape chunk lists;
+    halo: the halo frames).  The reference's CSV column of the same name is `payload_bytes` (:191), the bytes a rank
+    SENDS into `all_gather_object` (its own chunk list): both modes report that one as `info["payload_bytes"]`, and
+    a caller that writes the reference's CSV row (`metrics.csv_row`) passes it as the `network_bytes` column;
   * the linear-ramp blend (:204-217) runs on the device, in the reference's accumulation order.
 """
 from __future__ import annotations
@@ -366,6 +372,7 @@ class DistributedVideoDiffuser:
             self._sync()
             info["net_gather_s"] = time.time() - t0
             info["network_bytes"] = (self.world - 1) * cp.per_rank * C * cp.chunk * H * W * 2    # received per rank
+            info["payload_bytes"] = sum(t.numel() * 2 for t in mine)                             # the reference's :191
             return self.blend(chunks, base, cp.overlap), info
         if exchange != "halo":
             raise ValueError(f"unknown exchange {exchange!r}")
@@ -375,5 +382,6 @@ class DistributedVideoDiffuser:
         self._sync()
         info["net_gather_s"] = time.time() - t0
         info["network_bytes"] = sum(t.numel() * 2 for t in got.values())
+        info["payload_bytes"] = sum(t.numel() * 2 for t in mine)                                 # the reference's :191
         info["owned"] = [(s, e) for s, e, _ in owned]
         return owned, info

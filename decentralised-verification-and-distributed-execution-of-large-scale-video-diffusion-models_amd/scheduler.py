@@ -39,7 +39,6 @@ class DDIMScheduler:
         self.num_inference_steps = None
         self.timesteps = None
         self._host_timesteps = None
-        self._cursor = 0
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         n_train = self.config.num_train_timesteps
@@ -51,7 +50,6 @@ class DDIMScheduler:
         ts += self.config.steps_offset
         self._host_timesteps = [int(t) for t in ts]
         self.timesteps = torch.from_numpy(ts).to(device)
-        self._cursor = 0
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -64,15 +62,22 @@ class DDIMScheduler:
         return (float((1 - a_t) ** 0.5), float(a_t ** 0.5), float(a_prev ** 0.5), float((1 - a_prev) ** 0.5))
 
     def _host_timestep(self, timestep) -> int:
-        """The step's timestep as a host integer WITHOUT reading device memory.  The reference hands `step` the 0-d
-        device tensors it iterates over (`for t in scheduler.timesteps`, :132,142); `int(t)` on those is a device
-        sync per step.  Like diffusers' own step-index bookkeeping, a device-tensor timestep is taken to be the next
-        one of the schedule (wrapping after the last: the reference runs `_denoise` once per chunk, :186-189);
-        Python numbers and host tensors are used as given."""
+        """The step's timestep as a host integer, by VALUE (diffusers semantics) and — for the tensors the reference
+        hands in — without reading device memory.  The reference passes `step` the 0-d device tensors it iterates
+        over (`for t in scheduler.timesteps`, :132,142); `int(t)` on those is a device sync per step.  Such an element
+        is a view of `self.timesteps`' storage, so its index is its address: (data_ptr - base) / itemsize, checked
+        against the storage's extent.  Any other device tensor (a clone, arithmetic on a timestep, a foreign schedule)
+        is read with `int(t)` — one sync, never a guess.  Python numbers and host tensors are used as given."""
         if torch.is_tensor(timestep) and timestep.is_cuda:
-            t = self._host_timesteps[self._cursor % len(self._host_timesteps)]
-            self._cursor += 1
-            return t
+            ts = self.timesteps
+            if ts is not None and ts.is_cuda and timestep.numel() == 1 and timestep.dtype == ts.dtype \
+                    and timestep.device == ts.device \
+                    and timestep.untyped_storage().data_ptr() == ts.untyped_storage().data_ptr():
+                off = timestep.data_ptr() - ts.data_ptr()
+                idx, rem = divmod(off, ts.element_size())
+                if rem == 0 and 0 <= idx < ts.numel():
+                    return self._host_timesteps[idx]
+            return int(timestep)
         return int(timestep)
 
     def step(self, model_output, timestep, sample, eta: float = 0.0, **_unused):

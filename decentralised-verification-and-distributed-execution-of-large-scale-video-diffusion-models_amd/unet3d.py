@@ -104,6 +104,8 @@ class UNet3DConditionModel(nn.Module):
 
         def get(k):
             used.add(k)
+            if k not in sd:
+                raise VdxError(f"missing key in state dict: {k}")
             return sd[k]
 
         def lin(prefix, bias=True):
@@ -525,8 +527,8 @@ class UNet3DConditionModel(nn.Module):
         if Cin != c.in_channels:
             raise VdxError(f"sample has {Cin} channels, model expects {c.in_channels}")
         nlev = len(c.block_out_channels)
-        if H % (2 ** (nlev - 1)) or Wd % (2 ** (nlev - 1)):
-            raise VdxError("latent height/width must be divisible by 8 (explicit upsample_size is not implemented)")
+        # (a latent whose height or width is not divisible by 2^(levels-1) takes diffusers' `upsample_size` path: every
+        # upsampler then resizes to the resolution of the skip tensor it will meet)
         if F > 128:
             raise VdxError("temporal attention kernel handles at most 128 frames per chunk")
         sample = sample.to(torch.float16).contiguous()
@@ -534,16 +536,23 @@ class UNet3DConditionModel(nn.Module):
         if ehs.shape[0] != B or ehs.shape[2] != c.cross_attention_dim or ehs.shape[1] > TEXT_PAD:
             raise VdxError(f"encoder_hidden_states shape {tuple(ehs.shape)} does not fit (B={B}, dim={c.cross_attention_dim})")
         self._text_len = ehs.shape[1]
-        # The text keys / values of the 16 cross-attentions depend on the prompt only: they are projected on the first
-        # step and kept while the caller keeps passing the SAME tensor object, unmodified (the denoising loop hands the
-        # same `emb` to all 50 steps, fsdp_chunked_coherent.py:138-140).  Identity + version, not the address: a new
-        # tensor may reuse a freed address with other contents.
+        # The text keys / values of the 16 cross-attentions depend on the prompt only: they are projected once and kept
+        # while the caller keeps passing the SAME tensor object, unmodified (identity + version, not the address: a new
+        # tensor may reuse a freed address with other contents).  `pipeline.denoise` and bench.py pass one tensor for
+        # all steps and hit the cache.  The reference's own loop rebuilds `emb = torch.cat([uncond, cond])` inside
+        # every step (fsdp_chunked_coherent.py:138): on the unchanged script each step is a miss — 32 small K / V
+        # projections and one padded copy, ~0.2 ms of a 180 ms step — never a stale hit.  Tensors without a version
+        # counter (inference mode) are not cached.
         ref = self._text_ref
-        if not (ref is not None and ref[0] is encoder_hidden_states and ref[1] == encoder_hidden_states._version
+        try:
+            ver = encoder_hidden_states._version
+        except Exception:       # inference-mode tensors do not track versions
+            ver = None
+        if not (ref is not None and ver is not None and ref[0] is encoder_hidden_states and ref[1] == ver
                 and ref[2] == (B, dev)):
             ehs_pad = torch.zeros((B * TEXT_PAD, c.cross_attention_dim), dtype=torch.float16, device=dev)
             ehs_pad.view(B, TEXT_PAD, -1)[:, :ehs.shape[1]] = ehs
-            self._text_ref = (encoder_hidden_states, encoder_hidden_states._version, (B, dev), ehs_pad)
+            self._text_ref = (encoder_hidden_states, ver, (B, dev), ehs_pad)
             self._text_kv = {}
         ehs_pad = self._text_ref[3]
         n_img = B * F
@@ -595,9 +604,16 @@ class UNet3DConditionModel(nn.Module):
                     x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs_pad, n_img, F, hh, ww)
                     x = self._temporal_transformer(f"{p}.temp_attentions.{j}", x, B, F, hh * ww, x.shape[1] // 64)
             if i != nlev - 1:
-                x = ops.gemm(x, W[f"{p}.upsamplers.0.conv.weight"], M=n_img * 4 * hh * ww, mode=ops.CONV3X3,
-                             bias=W[f"{p}.upsamplers.0.conv.bias"], conv=(n_img, hh, ww, 2 * hh, 2 * ww, 1, True))
-                hh, ww = 2 * hh, 2 * ww
+                th, tw = skips[-1][1], skips[-1][2]          # resolution of the next block's skip tensors
+                if (th, tw) == (2 * hh, 2 * ww):
+                    mode_up = 1                               # nearest x2, folded into the conv's gather
+                elif hh <= th <= 2 * hh and ww <= tw <= 2 * ww:
+                    mode_up = 2                               # F.interpolate(size=skip resolution, mode="nearest"), folded likewise
+                else:
+                    raise VdxError(f"upsampler {p}: {hh}x{ww} -> {th}x{tw}")
+                x = ops.gemm(x, W[f"{p}.upsamplers.0.conv.weight"], M=n_img * th * tw, mode=ops.CONV3X3,
+                             bias=W[f"{p}.upsamplers.0.conv.bias"], conv=(n_img, hh, ww, th, tw, 1, mode_up))
+                hh, ww = th, tw
         # out
         n = ops.groupnorm(x, W["conv_norm_out.weight"], W["conv_norm_out.bias"], groups=c.norm_num_groups,
                           n_samples=n_img, rows_per_sample=hh * ww, eps=c.norm_eps, silu_act=True)

@@ -78,6 +78,8 @@ class AutoencoderKL(nn.Module):
 
         def get(k):
             used.add(k)
+            if k not in sd:
+                raise VdxError(f"missing key in state dict: {k}")
             return sd[k].to(dev)
 
         def norm(p):

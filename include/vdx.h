@@ -59,7 +59,8 @@ typedef struct vdx_gemm_args {
     int32_t h_in, w_in;   /* conv3x3: source image size (rows of `a` = n*h_in*w_in)              */
     int32_t h_out, w_out; /* conv3x3: output image size (M = n*h_out*w_out)                      */
     int32_t stride;       /* conv3x3: 1 or 2 (pad 1)                                             */
-    int32_t upsample;     /* conv3x3: 1 = source is nearest-x2 upsampled on the fly              */
+    int32_t upsample;     /* conv3x3: 1 = source is nearest-x2 upsampled on the fly; 2 = nearest-upsampled to
+                           * (h_out, w_out) — diffusers' `upsample_size` path for latents not divisible by 8 */
     int32_t frames, hw;   /* tconv3: M = b*frames*hw, taps step `hw` rows, zero pad in time      */
     int32_t rows_per_bias2, ldb2; /* bias2 row = m / rows_per_bias2, row stride ldb2 elements        */
     int32_t epilogue;     /* VDX_EPI_* flags                                                     */
@@ -136,7 +137,10 @@ int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* bet
  *   vt : fp16 [heads*64][ldvt]  V transposed: vt[h*64+d][kvb*skv_pad + key]
  *   kv batch of sequence s is s / seq_per_kv (cross-attn: all frames of a sample share text).
  *   causal != 0: query i sees keys <= i only (CLIPTextModel's self-attention, fsdp_chunked_coherent.py:102).
- *   out: fp16 rows [n_seq*sq][ldo].                                                            */
+ *   out: fp16 rows [n_seq*sq][ldo].
+ *   Supported score range: |q.k * scale| <= 5000 nat.  The kernel's lazy softmax offset is carried as an fp16 MFMA
+ *   operand; up to that magnitude its spacing (<= 4 exp2-units) keeps a re-centred row inside the window in which
+ *   no further move is needed; it is clamped at +-60000 exp2-units, beyond ~11000 nat rows can stay mis-centred.  */
 int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                        void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
                        int seq_per_kv, float scale, int causal, vdx_stream_t stream);

@@ -131,3 +131,52 @@ def test_hash_tokenizer_and_scheduler_surface():
     s = d.DDIMScheduler()
     s.set_timesteps(50, device="cpu")
     assert s.init_noise_sigma == 1.0 and [int(t) for t in s.timesteps[:2]] == [981, 961]
+
+
+def test_from_pretrained_reads_a_local_checkpoint_directory(tmp_path):
+    """`DiffusionPipeline.from_pretrained(<dir>)` (`fsdp_chunked_coherent.py:55-61`) on a diffusers-layout directory
+    written here at narrow widths: the widths come from the directory's own config.json files (not from the Zeroscope
+    defaults), the .safetensors weights are ingested strictly (a missing or an unexpected key raises), 1x1 projections
+    stored as Conv2d weights are accepted, scheduler_config.json reaches the scheduler, and configurations the kernels
+    are not built for are refused instead of loaded wrong."""
+    import json
+    import os
+    from safetensors.torch import load_file, save_file
+    import ckpt_dir
+    from vdx._lib import VdxError
+    from vdx.compat import diffusers_shim as d
+    root = str(tmp_path / "ckpt")
+    usd = ckpt_dir.write(root)
+    pipe = d.DiffusionPipeline.from_pretrained(root, torch_dtype=torch.float16, low_cpu_mem_usage=True, use_safetensors=False,
+                                               device_map=None)
+    assert not pipe.synthetic_weights
+    assert pipe.unet.cfg.block_out_channels == ckpt_dir.UNET_CH and pipe.unet.cfg.cross_attention_dim == ckpt_dir.CROSS
+    assert pipe.unet.cfg.transformer_in_heads == 8 and pipe.unet.config.in_channels == 4
+    assert pipe.vae.cfg.block_out_channels == ckpt_dir.VAE_CH and pipe.vae.config.scaling_factor == 0.18215
+    assert pipe.text_encoder.cfg.hidden_size == 128 and pipe.text_encoder.cfg.num_hidden_layers == 2
+    assert pipe.scheduler.config.steps_offset == 1 and pipe.scheduler.config.beta_end == 0.012
+    # the conv-shaped projection was packed like the Linear one
+    k = "down_blocks.0.attentions.0.proj_in.weight"
+    assert usd[k].dim() == 4 and torch.equal(pipe.unet.W[k], usd[k].reshape(usd[k].shape[0], -1))
+    # strict: unexpected and missing keys
+    f = os.path.join(root, "unet", "diffusion_pytorch_model.safetensors")
+    sd = load_file(f)
+    save_file(dict(sd, **{"bogus.weight": torch.zeros(2)}), f)
+    with pytest.raises(VdxError, match="unexpected"):
+        d.DiffusionPipeline.from_pretrained(root)
+    sd.pop("mid_block.resnets.1.conv2.bias")
+    save_file(sd, f)
+    with pytest.raises(VdxError, match="missing key"):
+        d.DiffusionPipeline.from_pretrained(root)
+    # refused configurations
+    ckpt_dir.write(root)
+    cfgf = os.path.join(root, "unet", "config.json")
+    cfg = json.load(open(cfgf))
+    json.dump(dict(cfg, attention_head_dim=8), open(cfgf, "w"))
+    with pytest.raises(ValueError, match="attention_head_dim"):
+        d.DiffusionPipeline.from_pretrained(root)
+    json.dump(cfg, open(cfgf, "w"))
+    tcf = os.path.join(root, "text_encoder", "config.json")
+    json.dump(dict(json.load(open(tcf)), hidden_act="quick_gelu"), open(tcf, "w"))
+    with pytest.raises(ValueError, match="hidden_act"):
+        d.DiffusionPipeline.from_pretrained(root)

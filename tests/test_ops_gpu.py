@@ -395,7 +395,8 @@ def test_flash_attention_large_scores_online_rescale(gpu):
 
 @pytest.mark.parametrize("case", ["all_very_negative", "all_very_positive", "late_spike_up", "drift_down_then_up",
                                   "all_minus_150_nat", "tile0_spike_plus_150_nat", "falling_60_nat_per_tile",
-                                  "rising_60_nat_per_tile", "first_tile_low_then_window"])
+                                  "rising_60_nat_per_tile", "first_tile_low_then_window", "all_plus_2500_nat",
+                                  "all_minus_2500_nat", "rising_700_nat_per_tile"])
 @pytest.mark.parametrize("s", [320, 640])
 def test_flash_attention_lazy_offset_branches(gpu, case, s):
     """The softmax offset is lazy (kept at 0 while row maxima of the scaled scores stay in (-4, 10]).
@@ -417,7 +418,8 @@ def test_flash_attention_lazy_offset_branches(gpu, case, s):
     elif case == "late_spike_up":
         k[s - 20] = h(q.mean(0) * 40 + 3)      # one key far above the window in the last tile
     elif case in ("all_minus_150_nat", "tile0_spike_plus_150_nat", "falling_60_nat_per_tile",
-                  "rising_60_nat_per_tile", "first_tile_low_then_window"):
+                  "rising_60_nat_per_tile", "first_tile_low_then_window", "all_plus_2500_nat", "all_minus_2500_nat",
+                  "rising_700_nat_per_tile"):
         # Channel 0 carries an exact per-key shift of the scaled score: q[:,0] = 8 (4 on odd rows) and
         # scale 1/8 make the score of key j move by b[j] (b[j]/2) nat.  Softmax is shift-invariant, so the
         # fp32 reference stays finite on every one of these; a kernel whose offset can move DOWN by more
@@ -427,7 +429,12 @@ def test_flash_attention_lazy_offset_branches(gpu, case, s):
              "tile0_spike_plus_150_nat": torch.where(torch.arange(s) == 5, 150.0, 0.0),
              "falling_60_nat_per_tile": -60.0 * tile,
              "rising_60_nat_per_tile": 60.0 * tile,
-             "first_tile_low_then_window": torch.where(tile == 0, -40.0, 0.0)}[case]
+             "first_tile_low_then_window": torch.where(tile == 0, -40.0, 0.0),
+             # offsets beyond 2048 exp2-units, where the fp16 the offset is carried in has a spacing of 2 and 4: the
+             # re-centred running maximum then lands within +-1 / +-2 of zero, inside the window (include/vdx.h states
+             # the supported range: |score| <= 5000 nat)
+             "all_plus_2500_nat": torch.full((s,), 2500.0), "all_minus_2500_nat": torch.full((s,), -2500.0),
+             "rising_700_nat_per_tile": 700.0 * tile}[case]
         q[:, 0] = torch.where(torch.arange(s) % 2 == 0, 8.0, 4.0)
         k[:, 0] = b
     else:
@@ -677,6 +684,52 @@ def test_cfg_ddim_step_bit_exact(gpu, steps):
         scale = max(float(want.float().abs().max()), float(x0.float().abs().max()))
         assert float((got.float() - want.float()).abs().max()) <= 4 * 2.0 ** -10 * scale
         lat = want
+
+
+@pytest.mark.parametrize("hin,win,hout,wout", [(5, 8, 9, 15), (9, 15, 18, 30), (3, 3, 5, 6), (4, 4, 8, 8), (7, 2, 7, 3)])
+def test_conv3x3_upsample_to_size(gpu, hin, win, hout, wout):
+    """conv3x3 over a source nearest-upsampled to an explicit size (vdx_gemm_args.upsample = 2) against
+    F.interpolate(size=, mode="nearest") + F.conv2d."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(hin * 31 + wout)
+    n, cin, cout = 3, 64, 128
+    x = h(torch.randn(n, cin, hin, win, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / 24)
+    b = h(torch.randn(cout, generator=g) * 0.1)
+    ref = packing.nchw_to_rows(F.conv2d(F.interpolate(x, size=(hout, wout), mode="nearest"), w, b, padding=1))
+    out = ops.gemm(packing.nchw_to_rows(x).half().to(gpu), packing.pack_conv3x3(w.half()).to(gpu), M=n * hout * wout,
+                   mode=ops.CONV3X3, bias=b.half().to(gpu), conv=(n, hin, win, hout, wout, 1, 2))
+    close(out, ref)
+
+
+def test_scheduler_step_uses_the_timesteps_value(gpu):
+    """`DDIMScheduler.step` takes the timestep by VALUE (diffusers semantics), also out of sequence: elements of
+    `scheduler.timesteps` in any order (recognised by their storage address: no device read), copies of them and a
+    foreign device tensor (read with one sync), against host integers."""
+    _ops()
+    from vdx.scheduler import DDIMScheduler
+    s = DDIMScheduler()
+    s.set_timesteps(50, device=gpu)
+    g = torch.Generator().manual_seed(3)
+    eps = torch.randn(1, 4, 3, 8, 8, generator=g).half().to(gpu)
+    lat = torch.randn(1, 4, 3, 8, 8, generator=g).half().to(gpu)
+    host = [int(v) for v in s.timesteps.cpu()]
+    want = {t: s.step(eps, t, lat).prev_sample for t in set(host)}
+    for i in (0, 5, 2, 49, 5):                               # out of sequence, repeated
+        assert torch.equal(s.step(eps, s.timesteps[i], lat).prev_sample, want[host[i]])
+    for k, t in enumerate(s.timesteps[3:6]):                 # iteration over a slice: views of the same storage
+        assert torch.equal(s.step(eps, t, lat).prev_sample, want[host[3 + k]])
+    picked = s.timesteps[[0, 5, 2]]                          # advanced indexing copies: another storage
+    for k, i in enumerate((0, 5, 2)):
+        assert torch.equal(s.step(eps, picked[k], lat).prev_sample, want[host[i]])
+    assert torch.equal(s.step(eps, torch.tensor(host[7], device=gpu), lat).prev_sample, want[host[7]])
+    assert torch.equal(s.step_cfg(torch.cat([eps, eps]), s.timesteps[9], lat, 7.5),
+                       s.step_cfg(torch.cat([eps, eps]), host[9], lat, 7.5))
+    # a warm-up call with the first timestep does not shift the loop that follows (there is no cursor)
+    s.step(eps, s.timesteps[0], lat)
+    for i, t in enumerate(s.timesteps):
+        if i in (0, 1, 48, 49):
+            assert torch.equal(s.step(eps, t, lat).prev_sample, want[host[i]])
 
 
 def test_blend_bit_exact(gpu):
