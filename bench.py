@@ -119,6 +119,12 @@ def main():
                     help="rehearsal aid: gloo lets several ranks of a real multi-process job share ONE GPU (with --share-gpu); "
                          "the driver's runs use nccl (= RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal aid: every rank computes on cuda:0")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="distributed / rehearsal runs: gather the parameter shards through the C-ABI RCCL entry point "
+                         "(vdx_allgather_shard, vdx/comm.py) instead of the default peer-mapped copies")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="required with --backend gloo / --share-gpu / --frames / --resident: states that the line is a "
+                         "rehearsal, not a measurement of the BASELINE configuration (a driver run cannot take one by accident)")
     ap.add_argument("--peaked", action="store_true",
                     help="diagnostic: scale the spatial self-attention q|k projections x2 each (scores x4: row maxima tens of "
                          "nats above the mean, as trained checkpoints have) — the lazy softmax offset of the flash kernel then "
@@ -128,6 +134,8 @@ def main():
     ap.add_argument("--resident", action="store_true",
                     help="diagnostic: keep the UNet weights resident (no shard store) in a distributed / rehearsal run")
     args = ap.parse_args()
+    if (args.backend != "nccl" or args.share_gpu or args.frames or args.resident) and not args.rehearsal:
+        raise SystemExit("--backend gloo, --share-gpu, --frames and --resident change what is measured: pass --rehearsal with them")
 
     # stdout carries exactly ONE JSON line: libraries that print to fd 1 (RCCL's version banner)
     # are sent to stderr for the whole run.
@@ -172,7 +180,11 @@ def main():
             if k_.endswith(".attn1.to_qk.weight"):
                 w_.mul_(2.0)
     if dist_mode and not args.resident:
-        unet.shard_(rank, world)       # 1/N of every unit per GPU, per-unit RCCL all-gather
+        comm = None
+        if args.native_comm:
+            from vdx.comm import Comm
+            comm = Comm.from_torch(dev)
+        unet.shard_(rank, world, comm=comm)       # 1/N of every unit per GPU, gathered per unit on a side stream
     if args.ff_block_mb:
         unet.ff_block_bytes = args.ff_block_mb << 20
     sched = DDIMScheduler()
@@ -269,6 +281,39 @@ def main():
             "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
             "output_finite": finite,
         }
+        if hasattr(unet.W, "transport"):
+            out["shard_transport"] = "rccl-c-abi" if unet.W.comm is not None else unet.W.transport
+        if args.rehearsal or args.rehearse_dist:
+            out["rehearsal"] = True      # not the driver's measurement: one-GPU rehearsal of the distributed path / dev flags
+        if plan_world != world and args.rehearse_dist and my_frames != 24:
+            # The 1 -> N scaling target in one number, on ONE box and in ONE process (boxes of the pool differ by several
+            # per cent): N ranks each denoise a `my_frames`-frame window with sharded weights while one GPU alone takes
+            # t24 for the 24-frame clip; useful frames per step: N x 12 against 24.  The monolithic step
+            # is timed here on a second, resident copy of the same weights, after the rehearsal's memory peak was read.
+            unet24 = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
+            lat24 = seeded_noise((1, 4, 24, H, W), sched.init_noise_sigma, dev)
+
+            def step24(i, lat):
+                t = ts[i % len(ts)]
+                noise = unet24(ops.cfg_input(lat, None, 0.0), t, encoder_hidden_states=emb).sample
+                return sched.step_cfg(noise, t, lat, 7.5)
+
+            for i in range(max(args.warmup, 1)):
+                lat24 = step24(i, lat24)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                lat24 = step24(i, lat24)
+            torch.cuda.synchronize()
+            t24 = (time.perf_counter() - t1) / args.steps
+            tw = dt / args.steps
+            out[f"t{my_frames}_sharded_ms"] = round(1e3 * tw, 3)
+            out["t24_resident_ms"] = round(1e3 * t24, 3)
+            useful_per_rank = T / plan_world                      # frames of the video per rank and step
+            out["scaling_1_to_N_projected"] = round(plan_world * (useful_per_rank / 24.0) * t24 / tw, 3)
+            out["scaling_note"] = (f"{plan_world} ranks x {useful_per_rank:g} useful frames per step at t{my_frames}_sharded against 24 frames "
+                                   f"at t24_resident: {plan_world} x ({useful_per_rank:g} / 24) x t24 / t{my_frames}s; same process, same box")
+            del unet24
         if plan_world != world and hasattr(unet.W, "shards"):
             # one-GPU rehearsal of a rank of a bigger job: here the whole of every unit stays resident (world of one);
             # at the planned world size only 1/plan_world of the sharded bytes would.  Estimate, not a measurement.

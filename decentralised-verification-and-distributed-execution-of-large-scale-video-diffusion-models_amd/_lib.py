@@ -61,6 +61,10 @@ SIGNATURES = {
     "vdx_comm_destroy": (_i, [_vp]),
     "vdx_allgather_shard": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "vdx_halo_exchange": (_i, [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp]),
+    "vdx_ipc_export": (_i, [_vp, _vp, C.POINTER(_sz)]),
+    "vdx_ipc_open": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "vdx_ipc_close": (_i, [_vp, _sz]),
+    "vdx_peer_gather": (_i, [_vp, C.POINTER(_vp), _i, _sz, _vp]),
     "vdx_cfg_input_f16": (_i, [_vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "vdx_cfg_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),
     "vdx_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _sz, _vp]),

@@ -120,3 +120,51 @@ extern "C" int vdx_halo_exchange(vdx_comm* c, const void* send_buf, size_t send_
     if (e != ncclSuccess) return nccl_fail("halo_exchange", e);
     return e2 == ncclSuccess ? 0 : nccl_fail("halo_exchange", e2);
 }
+
+// ---- peer-mapped shards: the parameter gather as plain device-to-device copies (no collective, no kernel) ----------
+// Parameters never change after load, so a rank can PULL the other ranks' shards whenever it needs them — there is
+// nothing to rendezvous on.  Each rank exports the allocation that holds its shards once (vdx_ipc_export), opens the
+// other ranks' (vdx_ipc_open: the peer's memory becomes addressable here, peer access enabled lazily), and the gather
+// of a unit is `world` hipMemcpyAsync calls on the caller's side stream: the copy engines move the bytes over xGMI,
+// no compute unit is taken from the GEMMs that run meanwhile (RCCL's all-gather kernels hold CUs).
+extern "C" int vdx_ipc_export(const void* dev_ptr, void* handle64, size_t* offset_bytes) {
+    VDX_CHECK(dev_ptr && handle64 && offset_bytes, "ipc_export: null pointer");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+    void* base = nullptr;
+    size_t size = 0;
+    hipError_t e = hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)dev_ptr);
+    if (e != hipSuccess) return vdx_fail("ipc_export: hipMemGetAddressRange: %s", hipGetErrorString(e));
+    e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, base);
+    if (e != hipSuccess) return vdx_fail("ipc_export: hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    *offset_bytes = (size_t)((const char*)dev_ptr - (const char*)base);
+    return 0;
+}
+
+extern "C" int vdx_ipc_open(const void* handle64, size_t offset_bytes, void** dev_ptr) {
+    VDX_CHECK(handle64 && dev_ptr, "ipc_open: null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    void* base = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return vdx_fail("ipc_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    *dev_ptr = (char*)base + offset_bytes;
+    return 0;
+}
+
+extern "C" int vdx_ipc_close(void* dev_ptr, size_t offset_bytes) {
+    if (!dev_ptr) return 0;
+    const hipError_t e = hipIpcCloseMemHandle((char*)dev_ptr - offset_bytes);
+    return e == hipSuccess ? 0 : vdx_fail("ipc_close: %s", hipGetErrorString(e));
+}
+
+extern "C" int vdx_peer_gather(void* full, const void* const* srcs, int world, size_t shard_bytes, vdx_stream_t side_stream) {
+    VDX_CHECK(full && srcs && world > 0, "peer_gather: null pointer");
+    VDX_CHECK(shard_bytes > 0 && shard_bytes % 16 == 0, "peer_gather: shard of %zu bytes (must be a positive multiple of 16)", shard_bytes);
+    for (int r = 0; r < world; ++r) {
+        VDX_CHECK(srcs[r], "peer_gather: rank %d's shard is not mapped", r);
+        const hipError_t e = hipMemcpyAsync((char*)full + (size_t)r * shard_bytes, srcs[r], shard_bytes, hipMemcpyDeviceToDevice,
+                                            (hipStream_t)side_stream);
+        if (e != hipSuccess) return vdx_fail("peer_gather: copy from rank %d: %s", r, hipGetErrorString(e));
+    }
+    return 0;
+}

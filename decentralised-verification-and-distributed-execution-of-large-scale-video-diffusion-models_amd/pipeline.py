@@ -191,7 +191,8 @@ def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_strea
     """Send the frames other ranks own, receive the frames this rank owns from the windows other ranks denoised.
     Returns ({(chunk, s, e): tensor (1,C,e-s,H,W)}, event or None): the received pieces are valid on the current
     stream after `event.wait()` (GPU) or immediately (CPU).  `comm` (a `vdx.comm.Comm`): the transfers go through the
-    C-ABI entry point `vdx_halo_exchange` (RCCL send/recv), one call per transfer in the plan's global order."""
+    C-ABI entry point `vdx_halo_exchange` (RCCL send/recv), one grouped send + receive per neighbour.  (Executed with
+    more than one rank on no machine this build had: a one-GPU box cannot host two RCCL ranks.)"""
     cp = hp.cp
     ref = mine[0]
     _, C, _, H, W = ref.shape
@@ -216,8 +217,17 @@ def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_strea
         ready = torch.cuda.Event()
         ready.record(cur)
         side.wait_event(ready)
+        # one grouped send + receive per neighbour and call (include/vdx.h), neighbours in ascending order: with every
+        # rank walking its pairs in that order the pairs are met in one global (lexicographic) order — no cycle of waits
+        per_peer = {}
         for snd, to, rcv, frm in native:
-            comm.halo(snd, to, rcv, frm, side)
+            ent = per_peer.setdefault(to if snd is not None else frm, ([], []))
+            (ent[0] if snd is not None else ent[1]).append(snd if snd is not None else rcv)
+        for peer in sorted(per_peer):
+            snds, rcvs = per_peer[peer]
+            for k in range(max(len(snds), len(rcvs))):
+                comm.halo(snds[k] if k < len(snds) else None, peer if k < len(snds) else -1,
+                          rcvs[k] if k < len(rcvs) else None, peer if k < len(rcvs) else -1, side)
         done = torch.cuda.Event()
         done.record(side)
         for t_ in keep + list(got.values()):
@@ -349,10 +359,11 @@ class DistributedVideoDiffuser:
         if torch.device(self.cfg.device).type == "cuda":
             torch.cuda.synchronize()
 
-    def __call__(self, exchange: str = "allgather"):
+    def __call__(self, exchange: str = "allgather", comm=None):
         """exchange="allgather": every rank ends with the whole blended latent (reference semantics, :201-217)
         -> (lat fp32 (1,C,T,h,w), info).  exchange="halo": a rank ends with the frames it owns
-        -> ([(s, e, lat fp32 (1,C,e-s,h,w))], info) — the same bits, 1/world of the blend and decode work."""
+        -> ([(s, e, lat fp32 (1,C,e-s,h,w))], info) — the same bits, 1/world of the blend and decode work.
+        `comm` (vdx.comm.Comm): the halo transfers go through the C-ABI RCCL entry point instead of torch.distributed."""
         cfg = self.cfg
         T, H, W = cfg.num_frames, cfg.height // 8, cfg.width // 8
         cp = self.plan()
@@ -377,7 +388,7 @@ class DistributedVideoDiffuser:
         if exchange != "halo":
             raise ValueError(f"unknown exchange {exchange!r}")
         hp = HaloPlan(cp, T)
-        got, done = exchange_halos(mine, hp, self.rank) if self.world > 1 else ({}, None)
+        got, done = exchange_halos(mine, hp, self.rank, comm=comm) if self.world > 1 else ({}, None)
         owned = self.blend_owned(mine, hp, got, done, base)
         self._sync()
         info["net_gather_s"] = time.time() - t0

@@ -4,15 +4,27 @@ reference's `FSDP(pipe.unet, FULL_SHARD, ...)` wrap (`fsdp_chunked_coherent.py:6
 Every *unit* (one resnet, one temporal-conv stack, one spatial or temporal transformer, one
 resampler) owns a flat fp16 buffer; each GPU keeps 1/world of it.  During a forward the units are
 used strictly in order (`UNet3DConditionModel.unit_schedule`), so while unit k computes, unit k+1
-is all-gathered (RCCL over xGMI, `torch.distributed`) on a side HIP stream into the other of two
-gather buffers; a buffer is only overwritten after the compute stream has passed the unit that
-used it.  Inference only: no reduce-scatter.  Sharding changes memory, never results.
+is gathered on a side HIP stream into the other of two gather buffers; a buffer is only overwritten
+after the compute stream has passed the unit that used it.  Inference only: no reduce-scatter.
+Sharding changes memory, never results.
+
+Transports of the gather (`transport=`, env VDX_SHARD_TRANSPORT):
+  "peer"        (default on GPUs) the ranks' shard arenas are mapped into each other once (HIP IPC, `vdx_ipc_*`);
+                a gather is `world` device-to-device copies on the side stream (`vdx_peer_gather`): copy engines over
+                xGMI, NO compute unit taken from the GEMMs that run meanwhile, and no collective at all — parameters
+                are read-only after load, so a rank pulls what it needs when it needs it (SURVEY §5.8);
+  "collective"  `torch.distributed.all_gather_into_tensor` (backend "nccl" = RCCL: gather KERNELS on the side stream),
+                or `all_gather` over gloo (CPU tensors, tests); the fallback when the peer mapping cannot be set up;
+  comm=         the C-ABI RCCL entry point `vdx_allgather_shard` (vdx/comm.py).
 
 The store is a read-only mapping (name -> tensor view) and is what `UNet3DConditionModel.W`
 becomes after `shard_()`.  Works on CPU tensors with the `gloo` backend (used by the tests).
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import warnings
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -22,8 +34,7 @@ ALIGN = 64          # elements: keeps every view 128-byte aligned
 
 
 def _FORCE_COLLECTIVE():
-    """Rehearsal switch: issue the collective even for a world of 1 (bench.py --rehearse-dist)."""
-    import os
+    """Rehearsal switch: go through the gather transport even for a world of 1 (bench.py --rehearse-dist)."""
     return os.environ.get("VDX_SHARD_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
 
 
@@ -33,10 +44,11 @@ def _round_up(x, m):
 
 class ShardedStore:
     def __init__(self, tensors: Dict[str, torch.Tensor], unit_of: Callable[[str], Optional[str]],
-                 schedule: List[str], rank: int, world: int, group=None, comm=None):
+                 schedule: List[str], rank: int, world: int, group=None, comm=None, transport: Optional[str] = None):
         """`unit_of(name)` -> unit id, or None for tensors kept replicated (small stem tensors).
         `comm`: a `vdx.comm.Comm` — the gathers then go through the C-ABI (`vdx_allgather_shard`, RCCL) instead of
-        `torch.distributed`."""
+        `torch.distributed`.  `transport`: "peer" | "collective" (module docstring); default from VDX_SHARD_TRANSPORT,
+        else "peer" on GPUs."""
         self.rank, self.world, self.group, self.comm = rank, world, group, comm
         self.schedule = list(schedule)
         self._pos = {u: i for i, u in enumerate(self.schedule)}
@@ -57,25 +69,89 @@ class ShardedStore:
             self._unit_of[name] = u
             sizes[u] += _round_up(t.numel(), ALIGN)
         self._padded = {u: _round_up(max(n, 1), ALIGN * world) for u, n in sizes.items()}
-        # local shards
+        # local shards: ONE arena (the units' 1/world slices back to back, the same layout on every rank), so that one
+        # IPC export per rank makes all of them reachable
+        self._arena_off: Dict[str, int] = {}
+        off = 0
+        for u in self.schedule:
+            self._arena_off[u] = off
+            off += self._padded[u] // world
+        self._arena = torch.zeros(max(off, 1), dtype=self.dtype, device=self.device)
         self.shards: Dict[str, torch.Tensor] = {}
         for u in self.schedule:
             flat = torch.zeros(self._padded[u], dtype=self.dtype, device=self.device)
-            for name, off, shape in self._layout[u]:
-                flat[off:off + tensors[name].numel()] = tensors[name].reshape(-1)
+            for name, o, shape in self._layout[u]:
+                flat[o:o + tensors[name].numel()] = tensors[name].reshape(-1)
             n = self._padded[u] // world
-            self.shards[u] = flat[rank * n:(rank + 1) * n].clone()
+            self.shards[u] = self._arena[self._arena_off[u]:self._arena_off[u] + n]
+            self.shards[u].copy_(flat[rank * n:(rank + 1) * n])
             del flat
         cap = max(self._padded.values())
         self._bufs = [torch.empty(cap, dtype=self.dtype, device=self.device) for _ in range(2)]
         self._resident = [None, None]          # unit held by each buffer
         self._ready = [None, None]             # event: gather into buffer finished
         self._released = [None, None]          # event: compute stream is past the unit in that buffer
+        self._view_cache: Dict = {}            # (slot, unit) -> {name: view}: built once, not per switch
         self._views: Dict[str, torch.Tensor] = {}
         self._current: Optional[str] = None
         self._cuda = self.device.type == "cuda"
         self._side = torch.cuda.Stream(device=self.device) if self._cuda else None
         self.gathers = 0
+        self.transport = "collective"
+        self._peer_ptrs = None
+        want = transport or os.environ.get("VDX_SHARD_TRANSPORT") or ("peer" if self._cuda else "collective")
+        if want not in ("peer", "collective"):
+            raise ValueError(f"unknown shard transport {want!r}")
+        if want == "peer" and self._cuda and comm is None and (world > 1 or _FORCE_COLLECTIVE() or transport == "peer"):
+            self._setup_peer()
+
+    # ---- peer transport -----------------------------------------------------------------------
+    def _setup_peer(self):
+        """Map every other rank's arena into this process (collective over the group: handles travel by
+        all_gather_object).  Falls back to the collective transport, on every rank alike, if any rank fails."""
+        from . import _lib
+        lib = _lib.load()
+        torch.cuda.synchronize(self.device)          # the arena is complete before anybody may read it
+        handle, off = C.create_string_buffer(64), C.c_size_t(0)
+        rc = lib.vdx_ipc_export(self._arena.data_ptr(), handle, C.byref(off))
+        mine = (self.rank, os.getpid(), handle.raw if rc == 0 else None, off.value)
+        if self.world > 1:
+            infos = [None] * self.world
+            dist.all_gather_object(infos, mine, group=self.group)
+        else:
+            infos = [mine]
+        ptrs, opened, ok = [None] * self.world, [], all(i[2] is not None for i in infos)
+        if ok:
+            for r, pid, h, o in infos:
+                if r == self.rank:
+                    ptrs[r] = self._arena.data_ptr()
+                    continue
+                p = C.c_void_p()
+                if lib.vdx_ipc_open(h, o, C.byref(p)) != 0:
+                    ok = False
+                    break
+                ptrs[r] = p.value
+                opened.append((p.value, o))
+        if self.world > 1:       # everybody or nobody
+            flags = [None] * self.world
+            dist.all_gather_object(flags, ok, group=self.group)
+            ok = all(flags)
+        if not ok:
+            for p, o in opened:
+                lib.vdx_ipc_close(p, o)
+            msg = lib.vdx_last_error()
+            warnings.warn(f"ShardedStore: peer mapping of the shard arenas failed ({msg.decode() if msg else 'export failed'}); "
+                          "using the collective all-gather")
+            return
+        self._peer_ptrs, self._opened, self.transport = ptrs, opened, "peer"
+
+    def _peer_gather(self, out: torch.Tensor, unit: str):
+        from . import _lib
+        es = out.element_size()
+        n = self._padded[unit] // self.world
+        srcs = (C.c_void_p * self.world)(*[p + self._arena_off[unit] * es for p in self._peer_ptrs])
+        _lib.check(_lib.load().vdx_peer_gather(out.data_ptr(), srcs, self.world, n * es, self._side.cuda_stream),
+                   "vdx_peer_gather")
 
     # ---- mapping protocol -------------------------------------------------------------------
     def __contains__(self, name):
@@ -106,7 +182,9 @@ class ShardedStore:
         shard = self.shards[unit]
 
         def run():
-            if self.world == 1 and not _FORCE_COLLECTIVE() and self.comm is None:
+            if self.transport == "peer":
+                self._peer_gather(out, unit)
+            elif self.world == 1 and not _FORCE_COLLECTIVE() and self.comm is None:
                 out.copy_(shard)
             elif self._cuda and self.comm is not None:
                 self.comm.allgather(shard, out, self._side)
@@ -143,8 +221,12 @@ class ShardedStore:
             self._gather_into(slot, unit)
         if self._cuda and self._ready[slot] is not None:
             torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
-        buf = self._bufs[slot]
-        self._views = {name: buf[off:off + _numel(shape)].view(shape) for name, off, shape in self._layout[unit]}
+        views = self._view_cache.get((slot, unit))
+        if views is None:
+            buf = self._bufs[slot]
+            views = {name: buf[off:off + _numel(shape)].view(shape) for name, off, shape in self._layout[unit]}
+            self._view_cache[(slot, unit)] = views
+        self._views = views
         self._current = unit
         # prefetch the next unit of the schedule into the other buffer
         nxt = self.schedule[(self._pos[unit] + 1) % len(self.schedule)]

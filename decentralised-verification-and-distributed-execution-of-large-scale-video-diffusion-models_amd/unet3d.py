@@ -281,13 +281,14 @@ class UNet3DConditionModel(nn.Module):
             return ".".join(parts[:3])
         return None                              # conv_in/out, time embedding, conv_norm_out
 
-    def shard_(self, rank: int, world: int, group=None, comm=None):
+    def shard_(self, rank: int, world: int, group=None, comm=None, transport=None):
         """Keep 1/world of every unit on this GPU; gather per unit with prefetch (vdx/shard.py).  `comm`: gather through
-        the C-ABI RCCL entry point instead of torch.distributed (vdx/comm.py)."""
+        the C-ABI RCCL entry point instead of torch.distributed (vdx/comm.py); `transport`: "peer" (mapped shard arenas,
+        copy-engine pulls: the default on GPUs) or "collective"."""
         from .shard import ShardedStore
         if not isinstance(self.W, dict):
             raise VdxError("weights are already sharded")
-        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group, comm)
+        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group, comm, transport)
         self.ff_block_bytes = 128 << 20
         if self._device.type == "cuda":
             torch.cuda.empty_cache()

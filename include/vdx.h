@@ -216,6 +216,17 @@ int vdx_rows_to_u8_frames(const void* rows, int ld, size_t n_pixels, void* out_u
  *                        (either side may be 0 bytes) — the overlap frames of the post-loop exchange (:190-202)
  * Both enqueue on `side_stream` and return; the caller orders them against its compute stream with events. */
 typedef struct vdx_comm vdx_comm;
+/* Peer-mapped shards — the same parameter gather WITHOUT a collective and without compute units: weights
+ * are read-only after load, so every rank exports the allocation holding its shards once, maps the others', and pulls.
+ *   vdx_ipc_export : 64-byte HIP IPC handle of the allocation `dev_ptr` lies in + its byte offset inside it
+ *   vdx_ipc_open   : map a peer's export (another process; same or another GPU of the node) -> device pointer here
+ *   vdx_ipc_close  : unmap (pointer and offset as returned / passed above)
+ *   vdx_peer_gather: full[r*shard_bytes ..] = srcs[r][0 .. shard_bytes) for r < world, as device-to-device copies on
+ *                    `side_stream` (copy engines; srcs[own rank] = the local shard)                              */
+int vdx_ipc_export(const void* dev_ptr, void* handle64, size_t* offset_bytes);
+int vdx_ipc_open(const void* handle64, size_t offset_bytes, void** dev_ptr);
+int vdx_ipc_close(void* dev_ptr, size_t offset_bytes);
+int vdx_peer_gather(void* full, const void* const* srcs, int world, size_t shard_bytes, vdx_stream_t side_stream);
 int vdx_comm_unique_id(void* id128);
 int vdx_comm_init(const void* id128, int rank, int world, vdx_comm** out);
 int vdx_comm_destroy(vdx_comm* comm);

@@ -37,6 +37,9 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     m, emb = build(dev, rank, world)
+    want_transport = os.environ.get("VDX_SHARD_TRANSPORT", "peer")
+    if world > 1:
+        assert m.W.transport == want_transport, (m.W.transport, want_transport)
     cfg = DiffuserConfig(num_frames=T, steps=steps, chunk_size=chunk, overlap=ov, height=256, width=256, mode=mode,
                          device="cuda", noise_device="cpu")
     d = DistributedVideoDiffuser(cfg, m, DDIMScheduler(), emb[1:], emb[:1])
@@ -51,7 +54,8 @@ def main():
     assert bool((counts == 1).all()), counts
     if rank == 0:
         torch.save({"lat": full.cpu(), "ranges": [tuple(r) for r in info["ranges"]], "overlap": info["overlap"],
-                    "gathers": getattr(m.W, "gathers", None), "halo_bytes": info2["network_bytes"]}, out)
+                    "gathers": getattr(m.W, "gathers", None), "halo_bytes": info2["network_bytes"],
+                    "transport": getattr(m.W, "transport", None)}, out)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok", flush=True)

@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,mode,T,chunk,ov", [(2, "hybrid_ctx", 20, 0, 4), (3, "hybrid", 17, 6, 2), (2, "fsdp", 6, 0, 4)])
-def test_multi_process_job_equals_serial_job_bitwise(gpu, tmp_path, world, mode, T, chunk, ov):
+@pytest.mark.parametrize("world,mode,T,chunk,ov,transport", [(2, "hybrid_ctx", 20, 0, 4, "peer"), (3, "hybrid", 17, 6, 2, "peer"),
+                                                             (2, "fsdp", 6, 0, 4, "peer"), (2, "hybrid_ctx", 20, 0, 4, "collective")])
+def test_multi_process_job_equals_serial_job_bitwise(gpu, tmp_path, world, mode, T, chunk, ov, transport):
+    """transport "peer": every rank maps the other ranks' shard arenas (HIP IPC between the processes) and gathers a unit
+    as device-to-device copies on its side stream — no collective, no gather kernel (vdx/shard.py, vdx_peer_gather);
+    "collective": torch.distributed all-gather (gloo here)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import vdx  # noqa: F401
     from dist_pipeline_worker import build
@@ -27,7 +31,8 @@ def test_multi_process_job_equals_serial_job_bitwise(gpu, tmp_path, world, mode,
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", str(29660 + world + T),
                         os.path.join(ROOT, "tests", "dist_pipeline_worker.py"), str(out), mode, str(T), str(chunk), str(ov),
-                        str(steps)], capture_output=True, text=True, timeout=900)
+                        str(steps)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, VDX_SHARD_TRANSPORT=transport))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == world
     got = torch.load(out, weights_only=True)
@@ -46,3 +51,4 @@ def test_multi_process_job_equals_serial_job_bitwise(gpu, tmp_path, world, mode,
     assert torch.equal(got["lat"], want.cpu())
     if world > 1 and got["gathers"] is not None:
         assert got["gathers"] > 0                     # the parameters really went through the per-unit gather
+        assert got["transport"] == transport

@@ -104,6 +104,28 @@ def test_unet_through_shard_store_matches_unsharded(gpu):
 
 
 @pytest.mark.gpu
+def test_peer_transport_world_of_one(gpu):
+    """The peer transport of the shard store with one rank: the arena is exported (vdx_ipc_export succeeds on the
+    caching allocator's block), every unit is gathered through vdx_peer_gather on the side stream, the UNet output keeps
+    its bits.  (Mapping another process's arena: tests/test_dist_gpu.py.)"""
+    import vdx  # noqa: F401
+    from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
+    from vdx.weights import synthetic_state_dict
+    cfg = UNet3DConfig(block_out_channels=(64, 128, 128, 128), cross_attention_dim=128, transformer_in_heads=2)
+    m = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, seed=5, device=gpu), device=gpu)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 3, 16, 16, generator=g).half().to(gpu)
+    e = torch.randn(2, 77, 128, generator=g).half().to(gpu)
+    want = m(x, 501, encoder_hidden_states=e).sample
+    m.shard_(0, 1, transport="peer")
+    assert m.W.transport == "peer"
+    for _ in range(2):
+        got = m(x, 501, encoder_hidden_states=e).sample
+        assert torch.equal(got, want)
+    assert m.W.gathers > 10
+
+
+@pytest.mark.gpu
 def test_native_rccl_entry_points_world_of_one(gpu):
     """`vdx_comm_init / vdx_allgather_shard / vdx_halo_exchange` (include/vdx.h; RCCL resolved at run time) with a world
     of ONE rank — the round trip a single-GPU box allows: the gather reproduces the shard, the shard store gathers its
