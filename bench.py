@@ -131,10 +131,15 @@ def main():
                          "has to move; the default synthetic weights give near-uniform attention, its best case")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--ff-block-mb", type=int, default=0, help="diagnostic: feed-forward row-block size of the memory-lean mode")
+    ap.add_argument("--no-lean", action="store_true",
+                    help="diagnostic: sharded weights WITHOUT the memory-lean execution order (row-blocked feed-forward, split attention, ...)")
+    ap.add_argument("--lean-parts", default=None,
+                    help="diagnostic: which optional parts of the memory-lean order stay on besides the row-blocked feed-forward: "
+                         "comma list of concat, attn (default: both)")
     ap.add_argument("--resident", action="store_true",
                     help="diagnostic: keep the UNet weights resident (no shard store) in a distributed / rehearsal run")
     args = ap.parse_args()
-    if (args.backend != "nccl" or args.share_gpu or args.frames or args.resident) and not args.rehearsal:
+    if (args.backend != "nccl" or args.share_gpu or args.frames or args.resident or args.no_lean or args.lean_parts is not None) and not args.rehearsal:
         raise SystemExit("--backend gloo, --share-gpu, --frames and --resident change what is measured: pass --rehearsal with them")
 
     # stdout carries exactly ONE JSON line: libraries that print to fd 1 (RCCL's version banner)
@@ -187,6 +192,10 @@ def main():
         unet.shard_(rank, world, comm=comm)       # 1/N of every unit per GPU, gathered per unit on a side stream
     if args.ff_block_mb:
         unet.ff_block_bytes = args.ff_block_mb << 20
+    if args.no_lean:
+        unet.ff_block_bytes = None
+    if args.lean_parts is not None:
+        unet.lean_concat, unet.lean_attn = "concat" in args.lean_parts, "attn" in args.lean_parts
     sched = DDIMScheduler()
     sched.set_timesteps(50, device=dev)
     plan_world, plan_rank = (args.as_world, args.as_rank) if (args.rehearse_dist and args.as_world) else (world, rank)

@@ -74,6 +74,8 @@ class UNet3DConditionModel(nn.Module):
         self._device = torch.device("cpu")
         self.dtype = torch.float16
         self.ff_block_bytes = None     # memory-lean feed-forward (see _ff); shard_() turns it on
+        self.lean_concat = True        # (with ff_block_bytes set) concat GroupNorm -> conv1 over pieces of whole frames
+        self.lean_attn = True          # (with ff_block_bytes set) spatial self-attention over image halves
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
         self._text_ref = None                  # (encoder_hidden_states object, its version, (B, device), padded copy)
         self._text_kv: Dict[str, tuple] = {}   # cross-attention K / V^T of that text, per transformer
@@ -318,7 +320,7 @@ class UNet3DConditionModel(nn.Module):
         geo = (n_img, hh, ww, hh, ww, 1, False)
         B = n_img // F
         pieces = 0
-        if self.ff_block_bytes and x2 is not None and M * cout * 2 > (64 << 20):
+        if self.ff_block_bytes and self.lean_concat and x2 is not None and M * cout * 2 > (64 << 20):
             # memory-lean mode, concat input (up path): the normalised concat [rows][C1 + C2] is the widest tensor of
             # the block; GroupNorm (4-D: statistics per image) -> conv1 runs over the images in pieces of whole frames
             # of ONE batch item (the time-embedding row of a piece is then row 0 of `temb_all[b:]`), sized to about
@@ -412,9 +414,12 @@ class UNet3DConditionModel(nn.Module):
         if Mp != M:
             ln[M:].zero_()
         ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
-        if S % 8 == 0 and self.ff_block_bytes and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (128 << 20):
+        if S % 8 == 0 and self.ff_block_bytes and self.lean_attn and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (256 << 20):
             # memory-lean mode: images are independent in the self-attention, so q|k, V^T and the attention run over
-            # the images in two halves and only half of those intermediates ([rows][2C] + [C][rows]) is alive at a time
+            # the images in two halves and only half of those intermediates ([rows][2C] + [C][rows]) is alive at a time.
+            # Only where they would set the peak: level 0 of a 24-frame clip (283 MB per [rows][C] tensor).  On the
+            # 16- / 12-frame windows of BASELINE cfg4 / cfg5 the halves cost 0.6 ms per step and do not lower the peak
+            # (measured: 4.55 GB with and without them, gpurun_out r3n) — the concat GroupNorm pieces do.
             o = torch.empty((M, C), dtype=torch.float16, device=x.device)
             hm, hn = M // 2, n_img // 2
             for r0 in (0, hm):
