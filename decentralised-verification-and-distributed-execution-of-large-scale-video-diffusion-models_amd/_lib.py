@@ -24,6 +24,7 @@ class GemmArgs(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("frames", C.c_int32), ("hw", C.c_int32),
         ("rows_per_bias2", C.c_int32), ("ldb2", C.c_int32), ("epilogue", C.c_int32),
         ("row_begin", C.c_int32), ("row_end", C.c_int32),
+        ("ksplit", C.c_int32), ("reserved0", C.c_int32), ("workspace", C.c_void_p),
     ]
 
 
@@ -35,6 +36,7 @@ SIGNATURES = {
     "vdx_version": (_i, []),
     "vdx_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
     "vdx_gemm_plan": (_i, [C.POINTER(GemmArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "vdx_gemm_plan_ksplit": (_i, [C.POINTER(GemmArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "vdx_softmax_rows_f16": (_i, [_vp, _i, _i, _i, _f, _vp]),
     "vdx_rows_to_u8_frames": (_i, [_vp, _i, _sz, _vp, _vp]),
     "vdx_im2col_in_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

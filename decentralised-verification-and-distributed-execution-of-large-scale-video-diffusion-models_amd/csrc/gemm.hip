@@ -132,6 +132,18 @@ struct Stager {
             }
         }
     }
+    // start the K walk at K tile kt (split-K slices)
+    __device__ __forceinline__ void seek(int kt) {
+        kw = kt * 64;
+        if (MODE == 0) {
+            kc = kw;
+        } else {
+            constexpr int T = MODE == 1 ? 9 : 3;
+            const int slice = kt / T;
+            tap = kt - slice * T;
+            kc = slice * 64;
+        }
+    }
     __device__ __forceinline__ void advance() {
         // K order of the gathers is (64-channel slice, tap, channel): all taps of one channel slice are
         // consumed back to back, so the shifted re-reads of the same source pixels hit the XCD's L2
@@ -166,7 +178,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15, fq = lane >> 4;
     const int nk = p.K >> 6;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // split-K (p.ksplit > 1): block = (tile, slice); the slices of a tile are neighbours, so they share an XCD's L2
+    int kt_lo = 0, kt_hi = nk, slab = 0;
+    if (p.ksplit > 1) {
+        slab = bid;
+        const int sl = bid % p.ksplit;
+        bid /= p.ksplit;
+        kt_lo = sl * nk / p.ksplit;
+        kt_hi = (sl + 1) * nk / p.ksplit;
+    }
     int mt_, nt_;
     gemm_tile_of(bid, p.ntm, p.ntn, mt_, nt_);
     const int m0 = p.m_begin + mt_ * BM, n0 = nt_ * BN;
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     if (GEGLU) gelu_tab_init(gelu, tid, NT);
     Stage sg;
     sg.setup(p, tid, m0, n0);
+    if (kt_lo) sg.seek(kt_lo);
     if (does_w) sg.issue_w(p, smem, 0);
     if (does_a) sg.issue_a(p, smem, 0);
     sg.advance();
@@ -187,9 +209,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();                      // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
     STAMP(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int cur = (kt - kt_lo) & 1;
+        const bool more = kt + 1 < kt_hi;
 #if !(defined(VDX_STAMPS) && VDX_ABL == 2)   // diagnostic ablation 2: no DMA inside the K loop
         // buffer cur^1 was last read before the previous barrier
 #if !(defined(VDX_STAMPS) && VDX_ABL == 5)    // ablation 5: no activation DMA in the loop
@@ -239,6 +261,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 
     STAMP(2);
+    if (p.ksplit > 1) {
+        // this slice's fp32 accumulators -> its slab, in register order ([accumulator][thread][4]: 16-byte coalesced
+        // stores); vdx_gemm_reduce_kernel adds the slabs of a tile in slice order and runs the epilogue
+        float* dst = p.partial + (size_t)slab * (NT * TM * TN * 4) + tid * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *(f32x4*)(dst + (i * TN + j) * NT * 4) = acc[i][j];
+        return;
+    }
     gemm_epilogue<TM, TN, GEGLU>(p, acc, m0 + wm * WTM, n0 + wn * WTN, frow, fq, gelu);
 #ifdef VDX_STAMPS
     __builtin_amdgcn_s_waitcnt(0);        // stores drained
@@ -269,6 +301,60 @@ static int launch(const GemmP& p, hipStream_t st) {
     q.ntm = ntm;
     hipLaunchKernelGGL(kern, dim3(ntm * q.ntn), dim3(WM * WN * 64), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16");
+}
+
+// ---- split-K tails -----------------------------------------------------------------------------
+// A product whose 256x320 tiles do not fill a whole number of rounds of 256 ends in a mostly idle round.  Its tail
+// (fewer than half a round of tiles) can instead be computed as `ksplit` K slices per tile — all CUs busy for 1/ksplit
+// of a tile time — followed by this reduction: one wave per (tile, wave of the tile) sums the slices' fp32 slabs in
+// slice order (fixed: deterministic) and runs the SAME epilogue code on the sum.  The 16-frame windows of BASELINE
+// cfg4 / cfg5 are where it pays (level 2: 288 tiles = 1.125 rounds).  It changes the summation order of those rows
+// (K slices accumulated separately, then added), so it is a per-call opt-in (vdx_gemm_args.ksplit).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64) void gemm_reduce_kernel(const GemmP p) {
+    constexpr int NT = WM * WN * 64, WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+    const int lane = threadIdx.x;
+    const int wave = blockIdx.x % (WM * WN), tile = blockIdx.x / (WM * WN);
+    int mt_, nt_;
+    gemm_tile_of(tile, p.ntm, p.ntn, mt_, nt_);
+    const int m0 = p.m_begin + mt_ * BM, n0 = nt_ * BN;
+    f32x4 acc[TM][TN];
+    const float* src = p.partial + (size_t)tile * p.ksplit * (NT * TM * TN * 4) + (wave * 64 + lane) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = *(const f32x4*)(src + (i * TN + j) * NT * 4);
+    for (int sl = 1; sl < p.ksplit; ++sl) {
+        const float* s2 = src + (size_t)sl * (NT * TM * TN * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 v = *(const f32x4*)(s2 + (i * TN + j) * NT * 4);
+                acc[i][j] = acc[i][j] + v;
+            }
+    }
+    gemm_epilogue<TM, TN, false>(p, acc, m0 + (wave / WN) * WTM, n0 + (wave % WN) * WTN, lane & 15, lane >> 4);
+}
+
+static constexpr size_t KSPLIT_SLAB_BYTES = 256 * 320 * 4;     // fp32 accumulators of one 256x320 tile
+
+template <int MODE>
+static int launch_ksplit(const GemmP& p, int ksplit, float* ws, hipStream_t st) {
+    constexpr int BM = 256, BN = 320, WM = 4, WN = 2;
+    constexpr int lds = 2 * (BM + BN) * 128;
+    auto kern = gemm_kernel<BM, BN, WM, WN, MODE, false, MODE != 0>;
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
+    GemmP q = p;
+    q.ntn = (p.N + BN - 1) / BN;
+    q.ntm = (p.M - p.m_begin + BM - 1) / BM;
+    q.ksplit = ksplit;
+    q.partial = ws;
+    const int tiles = q.ntm * q.ntn;
+    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(WM * WN * 64), lds, st, q);
+    hipLaunchKernelGGL((gemm_reduce_kernel<BM, BN, WM, WN>), dim3(tiles * WM * WN), dim3(64), 0, st, q);
+    return vdx_launch_status("vdx_gemm_f16 (split-K tail)");
 }
 
 // Kernel choice.  `force` (vdx_gemm_args.epilogue bits 8..11, a testing/tuning knob) pins a
@@ -307,8 +393,10 @@ static TileChoice choose_tile(long long rows, int N) {
 static int choose_split(int begin, int end, int N) {
     const long long rows = end - begin;
     const TileChoice whole = choose_tile(rows, N);
-    if (whole.v != 2) return 0;
     const int nt320 = (N + 319) / 320;
+    // (also when the WHOLE product prefers small tiles — 18 432 rows x 1280: 288 big tiles = two rounds for 1.125 — whole
+    // rounds of big tiles + a small-tile tail can still win: one round at 1.2 PFLOP/s + 160 small tiles)
+    if (whole.v != 2 && !(nt320 * 320 * 4 <= N * 5 && rows >= 1024)) return 0;
     const long long t256 = ((rows + 255) / 256) * nt320;
     const long long full = t256 / 256;
     if (full == 0 || t256 % 256 == 0) return 0;
@@ -365,7 +453,7 @@ static int gemm_prepare(const vdx_gemm_args* a, GemmP& p, bool& geglu, int& forc
     p.frames = a->frames; p.hw = a->hw; p.rpb2 = a->rows_per_bias2 > 0 ? a->rows_per_bias2 : 1;
     p.ldb2 = a->ldb2 > 0 ? a->ldb2 : a->N;
     VDX_CHECK(p.ldb2 % 8 == 0, "gemm: ldb2 must be a multiple of 8");
-    p.ntn = 0; p.ntm = 0;
+    p.ntn = 0; p.ntm = 0; p.ksplit = 0; p.partial = nullptr;
     geglu = (a->epilogue & VDX_EPI_GEGLU) != 0;
     force = (a->epilogue >> 8) & 15;   // kernel variant override (0 = automatic)
     if (geglu) {
@@ -416,6 +504,20 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
     int force, ws_family;
     if (const int rc = gemm_prepare(a, p, geglu, force, ws_family)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (a->ksplit > 1) {
+        const int nt320 = (p.N + 319) / 320;
+        const long long tiles = (long long)((p.M - p.m_begin + 255) / 256) * nt320;
+        VDX_CHECK(!geglu && (force == 0 || force == 2), "gemm: split-K runs the 256x320 tile without GEGLU");
+        VDX_CHECK(a->ksplit <= 16 && (p.K >> 6) / a->ksplit >= 2, "gemm: ksplit %d leaves fewer than two K tiles per slice (K = %d)", a->ksplit, p.K);
+        VDX_CHECK(nt320 * 320 * 4 <= p.N * 5, "gemm: split-K needs N = %d to fill 320-wide tiles", p.N);
+        VDX_CHECK(a->workspace && (uintptr_t)a->workspace % 16 == 0, "gemm: split-K needs a 16-byte aligned workspace");
+        VDX_CHECK(tiles * a->ksplit <= (1 << 20), "gemm: split-K grid too large");
+        switch (a->mode) {
+            case VDX_GEMM_PLAIN: return launch_ksplit<0>(p, a->ksplit, (float*)a->workspace, st);
+            case VDX_GEMM_CONV3X3: return launch_ksplit<1>(p, a->ksplit, (float*)a->workspace, st);
+            default: return launch_ksplit<2>(p, a->ksplit, (float*)a->workspace, st);
+        }
+    }
     if (ws_family) return vdx_gemm_ws_launch(p, ws_family, geglu, st);
     if (geglu) return pick_tile<0, true>(p, force, st);
     switch (a->mode) {
@@ -438,5 +540,45 @@ extern "C" int vdx_gemm_plan(const vdx_gemm_args* a, int32_t* variant, int32_t* 
     }
     *variant = force ? force : choose_tile(p.M - p.m_begin, p.N).v;
     if (!force) *split_row = choose_split(p.m_begin, p.M, p.N);
+    return 0;
+}
+
+// Split-K plan for a whole product (row_begin = row_end = 0): *split_row / *ksplit / *workspace_bytes such that rows
+// [0, split_row) as one ordinary call and rows [split_row, M) as one call with vdx_gemm_args.ksplit = *ksplit (and a
+// workspace of that many bytes) are expected to be faster than vdx_gemm_plan's best; *ksplit = 0: no.
+extern "C" int vdx_gemm_plan_ksplit(const vdx_gemm_args* a, int32_t* split_row, int32_t* ksplit, size_t* workspace_bytes) {
+    VDX_CHECK(split_row && ksplit && workspace_bytes, "gemm_plan_ksplit: null pointer");
+    GemmP p;
+    bool geglu;
+    int force, ws_family;
+    if (const int rc = gemm_prepare(a, p, geglu, force, ws_family)) return rc;
+    *split_row = 0; *ksplit = 0; *workspace_bytes = 0;
+    if (ws_family || geglu || force || p.m_begin != 0 || p.M != a->M) return 0;
+    const long long rows = p.M;
+    const int nt320 = (p.N + 319) / 320, nk = p.K >> 6;
+    if (!(nt320 * 320 * 4 <= p.N * 5 && rows >= 1024)) return 0;        // (choose_tile's `fits`: N fills 320-wide tiles)
+    const long long t256 = ((rows + 255) / 256) * nt320, full = t256 / 256;
+    if (full == 0 || t256 % 256 == 0) return 0;
+    const long long mt_main = full * 256 / nt320;
+    const long long split = mt_main * 256;
+    if (split >= rows) return 0;
+    const long long t = ((rows - split + 255) / 256) * nt320;          // tiles of the tail
+    int S = (int)(128 / t);            // (t * S <= 128 slabs of 327 680 bytes: the workspace stays <= 42 MB)
+    if (S > 8) S = 8;
+    if (S > nk / 4) S = nk / 4;
+    if (S < 2) return 0;
+    // costs in HUNDREDTHS of a 256x320 tile time (choose_tile counts tenths).  Slab traffic + reduction + its launch:
+    // ~ 25 us at 128 slabs (measured: 2048 x 1280 x 11520 as 32 tiles x 8 slices 90 us for 54 us of slices), against a
+    // tile time of 0.0375 us per unit of K (fitted at 1.1 PFLOP/s); a second launch ~ a tenth of a tile.
+    const long long main_c = 100 * ((mt_main * nt320 + 255) / 256);
+    const long long cost = main_c + (100 + S - 1) / S + (5 + 20 * t * S / 128) * 100 * 1000 / (37 * p.K) + 10;
+    // what vdx_gemm_plan would do: the whole product on its best tile, or whole rounds + a tail on small tiles
+    long long best = 10 * choose_tile(rows, p.N).cost;
+    const long long two = main_c + 10 * choose_tile(rows - split, p.N).cost + 10;
+    if (two < best) best = two;
+    if (cost * 100 > best * 97) return 0;
+    *split_row = (int32_t)split;
+    *ksplit = S;
+    *workspace_bytes = (size_t)t * S * KSPLIT_SLAB_BYTES;
     return 0;
 }

@@ -14,6 +14,8 @@ struct GemmP {
     int frames, hw, rpb2, ldb2;
     int ntn, ntm;
     int m_begin;      // first row computed (tiles start here)
+    int ksplit;       // > 1: every tile is computed by `ksplit` blocks, each over a slice of the K tiles, which leave their
+    float* partial;   //      fp32 accumulators in a slab of `partial`; vdx_gemm_reduce_kernel sums the slabs and runs the epilogue
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

@@ -48,9 +48,22 @@ def round_up(x: int, m: int) -> int:
 
 
 # --------------------------------------------------------------------------------------------
+_KSPLIT_WS = {}     # device -> fp32 workspace of the split-K tails (grown on demand; launches are stream-ordered)
+
+
+def _ksplit_workspace(device, nbytes):
+    ws = _KSPLIT_WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _KSPLIT_WS[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=0, residual=None,
-         out=None, geglu=False, conv=None, tconv=None, variant=0, row_begin=0, row_end=0):
-    """out[M][N] = epi(gather(a|a2)[M][K] @ w[N][K]^T).  See include/vdx.h `vdx_gemm_args`."""
+         out=None, geglu=False, conv=None, tconv=None, variant=0, row_begin=0, row_end=0, allow_ksplit=False, ksplit=0):
+    """out[M][N] = epi(gather(a|a2)[M][K] @ w[N][K]^T).  See include/vdx.h `vdx_gemm_args`.
+    `allow_ksplit`: the tail of the product (less than half a round of big tiles) may run as K slices + a fixed-order
+    reduction (vdx_gemm_plan_ksplit) — faster on the 16-frame windows, not bit-identical to the unsplit order (the
+    callers that rely on row-split bit-identity do not pass it).  `ksplit`: pin it for rows [row_begin, row_end)."""
     lib = _lib.load()
     ar, c1, lda = _rows(a, "a")
     N, K = w.shape
@@ -106,18 +119,27 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     g.epilogue = (EPI_GEGLU if geglu else 0) | ((variant & 15) << 8)   # variant: kernel override (tests/tuning)
     # One product, up to two launches: whole rounds of 256 big tiles, then the rest on whatever tile suits it
     # (vdx_gemm_plan; the bits do not depend on the split).  A pinned variant or an explicit row range is left alone.
-    spans = [(row_begin, row_end)]
-    if variant == 0 and row_begin == 0 and row_end == 0:
-        key = (M, N, K, mode, geglu, a2 is not None, bias2 is not None)      # everything the plan depends on
-        split = _PLAN_CACHE.get(key)
-        if split is None:
-            v_, split_ = C.c_int32(0), C.c_int32(0)
-            _lib.check(lib.vdx_gemm_plan(C.byref(g), C.byref(v_), C.byref(split_)), "vdx_gemm_plan")
-            split = _PLAN_CACHE[key] = split_.value
+    spans = [(row_begin, row_end, ksplit)]
+    if variant == 0 and row_begin == 0 and row_end == 0 and ksplit == 0:
+        key = (M, N, K, mode, geglu, a2 is not None, bias2 is not None, allow_ksplit)      # everything the plan depends on
+        plan_ = _PLAN_CACHE.get(key)
+        if plan_ is None:
+            v_, split_, ks_, wsb_ = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_size_t(0)
+            if allow_ksplit:
+                _lib.check(lib.vdx_gemm_plan_ksplit(C.byref(g), C.byref(split_), C.byref(ks_), C.byref(wsb_)), "vdx_gemm_plan_ksplit")
+            if ks_.value == 0:
+                _lib.check(lib.vdx_gemm_plan(C.byref(g), C.byref(v_), C.byref(split_)), "vdx_gemm_plan")
+            plan_ = _PLAN_CACHE[key] = (split_.value, ks_.value, wsb_.value)
+        split, ks, wsb = plan_
         if split:
-            spans = [(0, split), (split, 0)]
-    for rb, re_ in spans:
-        g.row_begin, g.row_end = rb, re_
+            spans = [(0, split, 0), (split, 0, ks)]
+    elif ksplit > 1:
+        nt = -(-((row_end or M) - row_begin) // 256) * -(-N // 320)
+        wsb = nt * ksplit * 327680
+    for rb, re_, ks in spans:
+        g.row_begin, g.row_end, g.ksplit, g.workspace = rb, re_, ks, None
+        if ks > 1:
+            g.workspace = _ksplit_workspace(out.device, wsb).data_ptr()
         if PROFILE is None:
             _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
             continue
@@ -129,6 +151,8 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
         rows = (re_ or M) - rb
         name = gemm_kernel_name(rows, N, K, mode, geglu, variant, single_source=a2 is None and bias2 is None,
                                 residual=residual is not None, whole=(rb == 0 and re_ in (0, M)))
+        if ks > 1:
+            name = f"gemm_kernel<256, 320, 4, 2, {mode}, false, {'true' if mode else 'false'}> split-K + reduce"
         PROFILE.append((name, 2.0 * rows * N * K, ev0, ev1, (rows, N, K)))
     return out
 

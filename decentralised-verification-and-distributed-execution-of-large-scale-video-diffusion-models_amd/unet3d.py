@@ -319,6 +319,7 @@ class UNet3DConditionModel(nn.Module):
             sc = x
         geo = (n_img, hh, ww, hh, ww, 1, False)
         B = n_img // F
+        concat_in = x2 is not None
         pieces = 0
         if self.ff_block_bytes and self.lean_concat and x2 is not None and M * cout * 2 > (64 << 20):
             # memory-lean mode, concat input (up path): the normalised concat [rows][C1 + C2] is the widest tensor of
@@ -346,12 +347,15 @@ class UNet3DConditionModel(nn.Module):
             h = ops.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=n_img,
                               rows_per_sample=S, eps=eps, silu_act=True, x2=x2)
             del x, x2
+            # (split-K tail allowed unless this is a product the memory-lean order cuts into pieces: a piece and the
+            # whole must keep the same summation order, the sharded forward has the bits of the resident one)
             h = ops.gemm(h, W[p + ".conv1.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
-                         bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, conv=geo)
+                         bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, conv=geo,
+                         allow_ksplit=not (concat_in and M * cout * 2 > (64 << 20)))
         h = ops.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups=g, n_samples=n_img,
                           rows_per_sample=S, eps=eps, silu_act=True)
         return ops.gemm(h, W[p + ".conv2.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv2.bias"],
-                        residual=sc, conv=geo)
+                        residual=sc, conv=geo, allow_ksplit=True)
 
     def _temp_conv(self, p, x, B, F, S):
         W, g = self.W, self.cfg.norm_num_groups
@@ -361,7 +365,7 @@ class UNet3DConditionModel(nn.Module):
             n = ops.groupnorm(y, W[f"{p}.conv{i}.0.weight"], W[f"{p}.conv{i}.0.bias"], groups=g, n_samples=B,
                               rows_per_sample=F * S, eps=1e-5, silu_act=True)
             y = ops.gemm(n, W[f"{p}.conv{i}.weight"], M=M, mode=ops.TCONV3, bias=W[f"{p}.conv{i}.bias"],
-                         tconv=(F, S), residual=x if i == 4 else None)
+                         tconv=(F, S), residual=x if i == 4 else None, allow_ksplit=True)
         return y
 
     # Temporaries are released as soon as their consumer has been enqueued (`del`): kernels run in stream order,
@@ -385,7 +389,8 @@ class UNet3DConditionModel(nn.Module):
             ln = ops.layernorm(t, W[b + ".norm3.weight"], W[b + ".norm3.bias"], M=M)
             gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=M, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
             del ln
-            return ops.gemm(gg, W[b + ".ff.net.2.weight"], M=M, bias=W[b + ".ff.net.2.bias"], residual=t)
+            return ops.gemm(gg, W[b + ".ff.net.2.weight"], M=M, bias=W[b + ".ff.net.2.bias"], residual=t,
+                            allow_ksplit=M * 8 * inner <= (256 << 20))      # (never a shape the lean order cuts into row blocks)
         out = torch.empty_like(t[:M])
         for r0 in range(0, M, blk):
             r1 = min(r0 + blk, M)
@@ -414,12 +419,11 @@ class UNet3DConditionModel(nn.Module):
         if Mp != M:
             ln[M:].zero_()
         ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
-        if S % 8 == 0 and self.ff_block_bytes and self.lean_attn and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (256 << 20):
+        if S % 8 == 0 and self.ff_block_bytes and self.lean_attn and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (128 << 20):
             # memory-lean mode: images are independent in the self-attention, so q|k, V^T and the attention run over
             # the images in two halves and only half of those intermediates ([rows][2C] + [C][rows]) is alive at a time.
-            # Only where they would set the peak: level 0 of a 24-frame clip (283 MB per [rows][C] tensor).  On the
-            # 16- / 12-frame windows of BASELINE cfg4 / cfg5 the halves cost 0.6 ms per step and do not lower the peak
-            # (measured: 4.55 GB with and without them, gpurun_out r3n) — the concat GroupNorm pieces do.
+            # (level 0 only: 0.6 ms per step on a 16-frame window for 45 MB of its peak — measured 4.33 against 4.374 GB
+            # with the concat pieces on, gpurun_out r3n — which is what keeps the per-device share under 15 %)
             o = torch.empty((M, C), dtype=torch.float16, device=x.device)
             hm, hn = M // 2, n_img // 2
             for r0 in (0, hm):
@@ -585,7 +589,7 @@ class UNet3DConditionModel(nn.Module):
             if i != nlev - 1:
                 ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
                 x = ops.gemm(x, W[f"{p}.downsamplers.0.conv.weight"], M=n_img * ho * wo, mode=ops.CONV3X3,
-                             bias=W[f"{p}.downsamplers.0.conv.bias"], conv=(n_img, hh, ww, ho, wo, 2, False))
+                             bias=W[f"{p}.downsamplers.0.conv.bias"], conv=(n_img, hh, ww, ho, wo, 2, False), allow_ksplit=True)
                 hh, ww = ho, wo
                 skips.append((x, hh, ww))
         # mid
@@ -618,7 +622,7 @@ class UNet3DConditionModel(nn.Module):
                 else:
                     raise VdxError(f"upsampler {p}: {hh}x{ww} -> {th}x{tw}")
                 x = ops.gemm(x, W[f"{p}.upsamplers.0.conv.weight"], M=n_img * th * tw, mode=ops.CONV3X3,
-                             bias=W[f"{p}.upsamplers.0.conv.bias"], conv=(n_img, hh, ww, th, tw, 1, mode_up))
+                             bias=W[f"{p}.upsamplers.0.conv.bias"], conv=(n_img, hh, ww, th, tw, 1, mode_up), allow_ksplit=True)
                 hh, ww = th, tw
         # out
         n = ops.groupnorm(x, W["conv_norm_out.weight"], W["conv_norm_out.bias"], groups=c.norm_num_groups,

@@ -68,6 +68,12 @@ typedef struct vdx_gemm_args {
                              still addresses row 0 and M stays the whole product's row count.  Lets a caller cover one
                              product with two calls that use different tile shapes (vdx_gemm_plan); the results are
                              bit-identical however the rows are split                                 */
+    int32_t ksplit;       /* > 1: the rows of this call are computed on 256x320 tiles as `ksplit` slices of K per tile
+                             (fp32 partial slabs in `workspace`) + a fixed-order reduction that runs the epilogue.  Fills
+                             the chip when the call has far fewer than 256 tiles (the tail of a product).  Changes the
+                             summation order of these rows (NOT bit-identical to ksplit = 0; deterministic)          */
+    int32_t reserved0;
+    void* workspace;      /* ksplit > 1: >= tiles * ksplit * 327 680 bytes (vdx_gemm_plan_ksplit), 16-byte aligned    */
 } vdx_gemm_args;
 
 int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream);
@@ -77,6 +83,11 @@ int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream);
  * which splitting the product into two calls ([row_begin, split_row) and [split_row, row_end)) is expected to be faster
  * (whole rounds of 256 big tiles + a tail of small ones instead of a mostly idle last round), or 0.                  */
 int vdx_gemm_plan(const vdx_gemm_args* a, int32_t* variant, int32_t* split_row);
+/* The same question with a split-K tail allowed (whole products only): rows [0, *split_row) as one ordinary call, rows
+ * [*split_row, M) as one call with ksplit = *ksplit and a workspace of *workspace_bytes; *ksplit = 0 when vdx_gemm_plan's
+ * answer is at least as good.  Pays on the 16-frame windows of BASELINE cfg4 / cfg5, whose row counts leave 1/8 - 1/2 of a
+ * round of big tiles (level 2: 288 tiles on 256 CUs).                                                              */
+int vdx_gemm_plan_ksplit(const vdx_gemm_args* a, int32_t* split_row, int32_t* ksplit, size_t* workspace_bytes);
 
 /* conv_in gather: (B,Cin,F,H,W) fp16 latent -> im2col rows [B*F*H*W][Kpad], K = (ky*3+kx)*Cin + ci,
  * zero padded to Kpad (multiple of 64); conv_in = this + vdx_gemm_f16 with w [Cout][Kpad]

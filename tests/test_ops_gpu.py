@@ -131,6 +131,116 @@ def test_gemm_row_ranges_are_bit_identical_to_the_whole_product(gpu, split, v_he
          bias=d(torch.randn(Co, generator=g)))
 
 
+@pytest.mark.parametrize("mode,ks", [("conv", 8), ("conv", 3), ("tconv", 4), ("plain", 2), ("plain2", 5)])
+def test_gemm_split_k_tail(gpu, mode, ks):
+    """vdx_gemm_args.ksplit: the rows of a call as `ks` K slices per 256x320 tile (fp32 slabs) + the fixed-order reduction
+    that runs the epilogue (bias, time-embedding rows, residual), for the conv / temporal-conv gathers and plain rows,
+    with row tails and a row range that starts inside the product; against fp32, against the unsplit kernel (same
+    values up to the fp32 summation order) and bitwise against itself."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(ks * 7 + len(mode))
+    if mode == "conv":
+        n, cin, cout, hh, ww = 5, 128, 320, 24, 20
+        x = h(torch.randn(n, cin, hh, ww, generator=g))
+        w = h(torch.randn(cout, cin, 3, 3, generator=g) / 30)
+        b = h(torch.randn(cout, generator=g) * 0.1)
+        temb = h(torch.randn(n, cout, generator=g) * 0.2)
+        res = h(torch.randn(n * hh * ww, cout, generator=g))
+        ref = packing.nchw_to_rows(F.conv2d(x, w, b, padding=1) + temb[:, :, None, None]) + res
+        kw = dict(a=packing.nchw_to_rows(x).half().to(gpu), w=packing.pack_conv3x3(w.half()).to(gpu), M=n * hh * ww,
+                  mode=ops.CONV3X3, bias=b.half().to(gpu), bias2=temb.half().to(gpu), rows_per_bias2=hh * ww,
+                  residual=res.half().to(gpu), conv=(n, hh, ww, hh, ww, 1, False))
+    elif mode == "tconv":
+        B, Fr, S, C = 2, 5, 130, 320
+        x5 = h(torch.randn(B, C, Fr, S, 1, generator=g))
+        w = h(torch.randn(C, C, 3, 1, 1, generator=g) / 30)
+        b = h(torch.randn(C, generator=g) * 0.1)
+        y = F.conv3d(x5, w, b, padding=(1, 0, 0))
+        ref = y.permute(0, 2, 3, 4, 1).reshape(B * Fr * S, C)
+        kw = dict(a=x5.permute(0, 2, 3, 4, 1).reshape(B * Fr * S, C).half().contiguous().to(gpu), w=packing.pack_tconv3(w.half()).to(gpu),
+                  M=B * Fr * S, mode=ops.TCONV3, bias=b.half().to(gpu), tconv=(Fr, S))
+    else:
+        M, N, K = (1500, 640, 2560) if mode == "plain" else (700, 1280, 5120)
+        a = h(torch.randn(M, K, generator=g))
+        w = h(torch.randn(N, K, generator=g) / 40)
+        b = h(torch.randn(N, generator=g) * 0.1)
+        res = h(torch.randn(M, N, generator=g))
+        ref = a @ w.t() + b + res
+        kw = dict(a=a.half().to(gpu), w=w.half().to(gpu), M=M, bias=b.half().to(gpu), residual=res.half().to(gpu))
+    M = kw["M"]
+    plain = ops.gemm(variant=2, **kw)
+    out = ops.gemm(ksplit=ks, **kw)
+    close(out, ref)
+    close(out, plain.float().cpu(), tol=2e-3)
+    assert torch.equal(out, ops.gemm(ksplit=ks, **kw))
+    # a row range that starts inside the product: rows before it stay untouched, rows in it equal the whole split-K product
+    rb = 256 * (M // 512)
+    part = torch.full_like(out, float("nan"))
+    ops.gemm(ksplit=ks, row_begin=rb, out=part, **kw)
+    assert torch.isnan(part[:rb].float()).all() and torch.equal(part[rb:], out[rb:])
+
+
+def test_gemm_split_k_plan(gpu):
+    """The planners on the shapes they were fitted for.  vdx_gemm_plan: the level-2 convolution of a 16-frame window
+    (18 432 rows, N = 1280: 288 big tiles = one round + 32) is cut into whole rounds of big tiles + a small-tile tail
+    although the product as a whole would prefer small tiles.  vdx_gemm_plan_ksplit: consistent answers (a split-K tail
+    only with >= 4 K tiles per slice and at most 128 slabs of workspace; none for products that fill their rounds, for
+    short K, for what the weights-stationary kernels take); ops.gemm(allow_ksplit=True) runs whatever is planned."""
+    ops, _ = _ops()
+    import ctypes as C
+    from vdx import _lib
+    lib = _lib.load()
+
+    def args(M, N, K, mode=0, taps=1):
+        g = _lib.GemmArgs()
+        dummy = torch.zeros(16, dtype=torch.float16, device=gpu).data_ptr()
+        g.a, g.w, g.out = dummy, dummy, dummy
+        g.M, g.N, g.K, g.mode, g.c1 = M, N, K, mode, K // taps
+        g.lda, g.ldo = K // taps, N
+        g.h_in = g.h_out = 16
+        g.w_in = g.w_out = 16
+        g.stride = 1
+        g.frames, g.hw = 16, M // (2 * 16) if mode == 2 else 1
+        return g
+
+    def plan_ks(*a, **k):
+        g = args(*a, **k)
+        s_, k_, w_ = C.c_int32(0), C.c_int32(0), C.c_size_t(0)
+        _lib.check(lib.vdx_gemm_plan_ksplit(C.byref(g), C.byref(s_), C.byref(k_), C.byref(w_)), "plan")
+        return s_.value, k_.value, w_.value
+
+    def plan(*a, **k):
+        g = args(*a, **k)
+        v_, s_ = C.c_int32(0), C.c_int32(0)
+        _lib.check(lib.vdx_gemm_plan(C.byref(g), C.byref(v_), C.byref(s_)), "plan")
+        return v_.value, s_.value
+    assert plan(18432, 1280, 11520, mode=1, taps=9) == (1, 16384)           # small tiles as a whole, big + small when split
+    assert plan(73728, 640, 5760, mode=1, taps=9) == (2, 65536)
+    assert plan(65536, 320, 2880, mode=1, taps=9) == (2, 0)                 # whole rounds
+    for shape in ((18432, 1280, 11520, 1, 9), (73728, 640, 5760, 1, 9), (65536, 320, 2880, 1, 9), (18432, 1280, 320, 0, 1),
+                  (18432, 1280, 23040, 1, 9)):
+        M, N, K, mode, taps = shape
+        split, ks, ws = plan_ks(M, N, K, mode=mode, taps=taps)
+        if ks:
+            t = -(-(M - split) // 256) * -(-N // 320)
+            assert ks >= 2 and (K // 64) // ks >= 4 and t * ks <= 128 and ws == t * ks * 327680 and split % 256 == 0
+        else:
+            assert (split, ws) == (0, 0)
+    assert plan_ks(65536, 320, 2880, mode=1, taps=9)[1] == 0 and plan_ks(18432, 1280, 320)[1] == 0
+    M, N, K = 18432, 1280, 5120
+    g = torch.Generator().manual_seed(1)
+    a = h(torch.randn(M, K, generator=g)).half().to(gpu)
+    w = (h(torch.randn(N, K, generator=g)) / 60).half().to(gpu)
+    rec = []
+    ops.PROFILE = rec
+    try:
+        out = ops.gemm(a, w, M=M, allow_ksplit=True)
+    finally:
+        ops.PROFILE = None
+    assert len(rec) == 2 and rec[0][4][0] == 16384 and rec[1][4][0] == M - 16384
+    close(out, a.float().cpu() @ w.float().cpu().t())
+
+
 def test_gemm_automatic_tail_split(gpu):
     """A 16-frame level-1 temporal conv (73 728 x 640, 2.25 rounds of 256x320 tiles): the automatic path runs two whole
     rounds + a 128x128 tail (vdx_gemm_plan) and returns the bits of the single 256x320 launch; bench.py's per-launch
