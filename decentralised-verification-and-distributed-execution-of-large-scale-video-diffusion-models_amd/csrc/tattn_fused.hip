@@ -382,11 +382,7 @@ struct K7 {
                 K7_P1_STEP(fb, fa, ks + 1, false)
             }
             // ---- attention of this head on the wave's 48 rows (G pixels x F frames), all in registers.
-            // For O = P.V two 16x16 accumulator tiles stacked along the contraction index (the keys) are ONE operand of
-            // v_mfma_f32_16x16x32_f16: element e < 4 of lane quad q4 is key 4*q4 + e of the first tile, e >= 4 key
-            // 16 + 4*q4 + (e - 4) of the second — the same permutation on the A and the B side, so the product is unchanged.
-            // (The same stacking of d tiles for S = K.Q^T gave wrong scores on the hardware — cause not established —
-            // so S keeps v_mfma_f32_16x16x16_f16, whose operand layout IS the accumulator layout.)
+            // (S and P.V on v_mfma_f32_16x16x16_f16, whose operand layout IS the accumulator layout.)
 #ifdef K7_ABL_NOATT
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt)
@@ -394,7 +390,7 @@ struct K7 {
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ohead[hg][qt][dt][e] = (f16)(aq[qt][dt][e] + ak[qt][dt][e] + av[qt][dt][e]);
-#elif !defined(K7_EXP_PAIRED_PV)      /* (experimental: P.V on 16x16x32 with stacked key tiles gave wrong results on hardware) */
+#else
             f16x4 qh[3][4], kh[3][4], vh[3][4];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -453,78 +449,6 @@ struct K7 {
 #pragma unroll
                     for (int kt = 0; kt < 3; ++kt)
                         if ((need >> (3 * qt + kt)) & 1) o = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[kt][dt], pt[kt], o, 0, 0, 0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ohead[hg][qt][dt][e] = (f16)o[e];
-                }
-            }
-#else
-            f16x4 qh[3][4], kh[3][4];        // [row tile][d tile]: lane = row, d = 4*q4 + e — the 16x16x16 operand layout
-            f16x8 v2[4];                     // [d tile]: keys of row tiles 0 and 1 stacked (see above)
-            f16x4 v1[4];                     //           keys of row tile 2
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        qh[i][j][e] = (f16)aq[i][j][e];
-                        kh[i][j][e] = (f16)ak[i][j][e];
-                    }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v2[j][e] = (f16)av[0][j][e];
-                    v2[j][4 + e] = (f16)av[1][j][e];
-                    v1[j][e] = (f16)av[2][j][e];
-                }
-#pragma unroll
-            for (int qt = 0; qt < 3; ++qt) {
-                // S^T[key][query] for the three key tiles: lane = query 16*qt + n16, regs = keys 16*kt + 4*q4 + e
-                f32x4 st[3];
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt) {
-                    st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        st[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kh[kt][j], qh[qt][j], st[kt], 0, 0, 0);
-                }
-                float mx = NEG_BIG_K7();
-                bool ok[3][4];
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ok[kt][e] = kpix[kt][e] == qpix[qt];
-                        mx = fmaxf(mx, ok[kt][e] ? st[kt][e] : NEG_BIG_K7());
-                    }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mc = mx * p.c;
-                float rs = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        st[kt][e] = ok[kt][e] ? __builtin_amdgcn_exp2f(st[kt][e] * p.c - mc) : 0.f;
-                        rs += st[kt][e];
-                    }
-                rs += __shfl_xor(rs, 16, 64);
-                rs += __shfl_xor(rs, 32, 64);
-                const float inv = 1.0f / rs;
-                f16x8 p2;                    // keys of tiles 0 and 1 stacked (as v2)
-                f16x4 p1;                    // keys of tile 2
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p2[e] = (f16)(st[0][e] * inv);
-                    p2[4 + e] = (f16)(st[1][e] * inv);
-                    p1[e] = (f16)(st[2][e] * inv);
-                }
-                // O^T[d][query] = sum over keys V^T[d][key] P^T[key][query]
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2[dt], p2, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x16f16(v1[dt], p1, o, 0, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ohead[hg][qt][dt][e] = (f16)o[e];
                 }
