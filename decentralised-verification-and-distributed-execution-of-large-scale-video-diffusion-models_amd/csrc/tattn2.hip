@@ -130,10 +130,25 @@ extern "C" int vdx_debug_read_k7b_stamps(void* dst) {
 #define K7B_T(idx)
 #endif
 
-// F4: F is a multiple of 4 — the 4 key rows a lane holds of a score tile (rows 16*kt + 4*q4 + e) then belong to ONE pixel, so
-// the block-diagonal mask needs one compare per key tile instead of four (F = 24, 16, 12, 8, 4, 48; the others: F4 = false).
-template <int INNER, bool F4>
+// FS, the frame specialisation.  24 / 16 / 12 (the BASELINE chunk lengths): F is a compile-time constant — score tiles of
+// 16 rows that share no pixel are not computed at all (F = 16: 3 of 9 tiles remain, F = 24: 7, F = 12: 7), tiles that lie
+// inside one pixel need no mask.  4: any F that is a multiple of 4 — the 4 key rows a lane holds of a score tile (rows
+// 16*kt + 4*q4 + e) then belong to ONE pixel, so the block-diagonal mask needs one compare per key tile instead of four
+// (F = 8, 4, 48).  1: any F | 48.
+template <int INNER, int FS>
 struct K7B {
+    static constexpr bool F4 = FS != 1;
+    // tile relations at a compile-time F (16-row tiles a, b of the 48-row group): do they share a pixel / lie in ONE pixel
+    static constexpr bool tiles_meet(int a, int b) {
+        if (FS < 12) return true;
+        const int alo = 16 * a / FS, ahi = (16 * a + 15) / FS, blo = 16 * b / FS, bhi = (16 * b + 15) / FS;
+        return !(ahi < blo || bhi < alo);
+    }
+    static constexpr bool tiles_pure(int a, int b) {
+        if (FS < 12) return false;
+        const int alo = 16 * a / FS, ahi = (16 * a + 15) / FS, blo = 16 * b / FS, bhi = (16 * b + 15) / FS;
+        return alo == ahi && blo == bhi && alo == blo;
+    }
     static constexpr int KS = INNER / 32;                 // MFMA k steps over the model width
     static constexpr int HEADS = INNER / 64;
     static constexpr int KM = KS / 2;                     // K-64 steps over the model width
@@ -495,6 +510,7 @@ struct K7B {
         f32x4 sc[3];
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
+            if (!tiles_meet(QT, kt)) continue;
             sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -503,27 +519,34 @@ struct K7B {
         const int qp = opaque(qpix[QT]);      // (recomputed per head: 36 compare masks kept across the heads do not fit the SGPRs)
         float mx = -1.0e30f;
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt)
+        for (int kt = 0; kt < 3; ++kt) {
+            if (!tiles_meet(QT, kt)) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sc[kt][e] = kpix[kt][F4 ? 0 : e] == qp ? sc[kt][e] : -1.0e30f;      // keys of other pixels: exp2 below gives exactly 0
+                if (!tiles_pure(QT, kt))
+                    sc[kt][e] = kpix[kt][F4 ? 0 : e] == qp ? sc[kt][e] : -1.0e30f;      // keys of other pixels: exp2 below gives exactly 0
                 mx = fmaxf(mx, sc[kt][e]);
             }
+        }
         mx = quad_max(mx);
         float rs = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt)
+        for (int kt = 0; kt < 3; ++kt) {
+            if (!tiles_meet(QT, kt)) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 sc[kt][e] = __builtin_amdgcn_exp2f(sc[kt][e] - mx);         // (the scale is in W_q)
                 rs += sc[kt][e];
             }
+        }
         rs = quad_sum(rs);
         const float inv = 1.0f / rs;
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt)
+        for (int kt = 0; kt < 3; ++kt) {
+            if (!tiles_meet(QT, kt)) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) st.pt[QT][kt][e] = (f16)(sc[kt][e] * inv);
+        }
     }
     // After the v pass: O^T[d][query] = V^T P^T: lane = query row, registers e = d 16*dt + 4*q4 + e.  Two d tiles side
     // by side are one B operand of the output projection (k index of W_o permuted to match: packing.pack_k7b).
@@ -549,6 +572,7 @@ struct K7B {
                 f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
+                    if (!tiles_meet(qt, kt)) continue;
                     o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[kt][2 * kk], st.pt[qt][kt], o0, 0, 0, 0);
                     o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[kt][2 * kk + 1], st.pt[qt][kt], o1, 0, 0, 0);
                 }
@@ -754,10 +778,10 @@ struct K7B {
     }
 };
 
-template <int INNER, bool F4>
+template <int INNER, int FS>
 __global__ __launch_bounds__(256, 1) void tattn2_kernel(const K7BP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    K7B<INNER, F4> k(p, smem);
+    K7B<INNER, FS> k(p, smem);
     k.run();
 }
 
@@ -769,7 +793,7 @@ extern "C" int vdx_temporal_attn_block2_supported(int inner, int F) {
 // bytes of the packed blob (vdx/packing.py pack_k7b): q|k|v units, output-projection units, fp32 q bias, fp32 output bias
 extern "C" size_t vdx_temporal_attn_block2_pack_bytes(int inner) {
     if (inner != 320) return 0;
-    return (size_t)K7B<320, true>::NUNITS * K7B<320, true>::UB + 2 * 320 * sizeof(float);
+    return (size_t)K7B<320, 1>::NUNITS * K7B<320, 1>::UB + 2 * 320 * sizeof(float);
 }
 
 extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* packed, float eps, void* out, int ldo,
@@ -780,7 +804,7 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     VDX_CHECK(ldt % 8 == 0 && ldo % 8 == 0 && ldt >= inner && ldo >= inner, "temporal_attn_block2: bad leading dims");
     VDX_CHECK((long long)B * F * HW < (1ll << 31), "temporal_attn_block2: too many rows");
     VDX_CHECK(((uintptr_t)t % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)packed % 16 == 0), "temporal_attn_block2: pointers must be 16-byte aligned");
-    typedef K7B<320, true> T;
+    typedef K7B<320, 1> T;
     K7BP p;
     p.t = (const f16*)t; p.out = (f16*)out;
     p.wqkv = (const char*)packed;
@@ -795,17 +819,21 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     p.fmagic = (65536 + F - 1) / F;
     p.eps = eps;
     constexpr int lds = T::XB + T::NU * T::UB;
+    void (*kern)(const K7BP) = F == 24 ? tattn2_kernel<320, 24> : F == 16 ? tattn2_kernel<320, 16> : F == 12 ? tattn2_kernel<320, 12>
+                               : F % 4 == 0 ? tattn2_kernel<320, 4> : tattn2_kernel<320, 1>;
     static const hipError_t attr_rc = [] {
-        hipError_t a = hipFuncSetAttribute((const void*)tattn2_kernel<320, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipError_t b = hipFuncSetAttribute((const void*)tattn2_kernel<320, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        return a != hipSuccess ? a : b;
+        hipError_t e = hipSuccess;
+        for (auto k : {tattn2_kernel<320, 24>, tattn2_kernel<320, 16>, tattn2_kernel<320, 12>, tattn2_kernel<320, 4>, tattn2_kernel<320, 1>}) {
+            const hipError_t r = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (r != hipSuccess) e = r;
+        }
+        return e;
     }();
     if (attr_rc != hipSuccess) return vdx_fail("temporal_attn_block2: cannot reserve %d bytes of LDS", lds);
     // persistent grid: every workgroup walks the same number of tiles (+-1), one workgroup per CU at most
     const int ncu = vdx_num_cus();
     const int rounds = (p.ntiles + ncu - 1) / ncu;
     const int grid = (p.ntiles + rounds - 1) / rounds;
-    if (F % 4 == 0) hipLaunchKernelGGL((tattn2_kernel<320, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((tattn2_kernel<320, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return vdx_launch_status("vdx_temporal_attn_block2_f16");
 }

@@ -41,7 +41,7 @@ def inflight(s): return 2 * (hm(s - 1) - ub(s + 2)) + younger(s)
 
 
 def check(text, label):
-    m = re.search(r"^(_ZN\S*tattn2_kernelILi320E" + label + r"\S*):", text, re.M)
+    m = re.search(r"^(_ZN\S*tattn2_kernelILi320E" + label + r"E\S*):", text, re.M)
     if not m:
         print("kernel", label, "not found")
         return 1
@@ -86,4 +86,4 @@ def check(text, label):
 
 if __name__ == "__main__":
     text = open(sys.argv[1]).read()
-    sys.exit(1 if sum(check(text, lb) for lb in ("Lb1E", "Lb0E")) else 0)
+    sys.exit(1 if sum(check(text, lb) for lb in ("Li24E", "Li16E", "Li12E", "Li4E", "Li1E")) else 0)
