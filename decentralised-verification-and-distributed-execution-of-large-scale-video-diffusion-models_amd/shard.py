@@ -144,6 +144,25 @@ class ShardedStore:
                           "using the collective all-gather")
             return
         self._peer_ptrs, self._opened, self.transport = ptrs, opened, "peer"
+        if self.world > 1:
+            # self-check, once: the first unit pulled through the mapped arenas must equal the same unit gathered by the
+            # collective (a mapping that opens but reads something else must not go unnoticed); everybody or nobody
+            unit = self.schedule[0]
+            n = self._padded[unit]
+            a, b = self._bufs[0][:n], self._bufs[1][:n]
+            with torch.cuda.stream(self._side):
+                self._peer_gather(a, unit)
+            self._side.synchronize()
+            if dist.get_backend(self.group) != "gloo":
+                dist.all_gather_into_tensor(b, self.shards[unit], group=self.group)
+            else:
+                dist.all_gather(list(b.chunk(self.world)), self.shards[unit], group=self.group)
+            torch.cuda.synchronize(self.device)
+            flags = [None] * self.world
+            dist.all_gather_object(flags, bool(torch.equal(a, b)), group=self.group)
+            if not all(flags):
+                warnings.warn("ShardedStore: the peer-mapped gather does not reproduce the collective one; using the collective all-gather")
+                self.transport = "collective"
 
     def _peer_gather(self, out: torch.Tensor, unit: str):
         from . import _lib
