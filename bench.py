@@ -182,8 +182,8 @@ def main():
     unet = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
     if args.peaked:
         for k_, w_ in unet.W.items():
-            if k_.endswith(".attn1.to_qk.weight"):
-                w_.mul_(2.0)
+            if k_.endswith(".attn1.to_qkv.weight") and ".transformer_blocks." in k_ and "temp_attentions" not in k_ and "transformer_in" not in k_:
+                w_[:2 * w_.shape[0] // 3].mul_(2.0)       # q and k rows of the spatial self-attention projections
     if dist_mode and not args.resident:
         comm = None
         if args.native_comm:

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vdx_groupnorm_part_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "vdx_layernorm_f16": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "vdx_flash_attn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "vdx_flash_attn_rows_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "vdx_timestep_embedding_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "vdx_gelu_f16": (_i, [_vp, _vp, _sz, _vp]),
     "vdx_temporal_attn_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),

@@ -8,8 +8,10 @@
 //     lane-local plus one exchange with lane^32, and the exponentiated tile is already the B
 //     operand of O^T = V^T.P^T (accumulator-as-operand, no LDS round trip for P).  K rows are fed
 //     in the bit-swapped order that makes that operand's permuted k-index the natural key order,
-//     so V^T fragments are plain 16-byte LDS reads.  V arrives pre-transposed ([d][key]): the V
-//     projection GEMM is simply issued with swapped operands.
+//     so V^T fragments are plain 16-byte LDS reads when V arrives pre-transposed ([d][key], VROW = false: the
+//     text K/V of cross-attention and the CLIP tower, projected once by a swapped GEMM).  VROW = true: V arrives
+//     as ROWS ([key][d], the third column block of one q|k|v projection), is staged like K and read through
+//     ds_read_b64_tr_b16 — the transposition happens in the LDS read, two 8-byte reads per operand.
 //   * Q is pre-scaled by scale*log2(e); the running maximum is folded INTO the score contraction by
 //     one extra k-step ([1,0,..] row of "K" times [-m,0,..] column of "Q"), so S' = S - m costs one
 //     MFMA per 32 keys and no per-score VALU op, and in the common tile p = exp2(S') directly.
@@ -22,7 +24,7 @@
 
 
 struct FlashP {
-    const f16 *q, *k, *vt;
+    const f16 *q, *k, *vt;   // vt: V^T [heads*64][ldvt]  (VROW: V rows [n_kv*skv_pad][ldvt])
     f16* out;
     int ldq, ldk, ldvt, ldo;
     int sq, skv, skv_pad, seq_per_kv, heads;
@@ -33,10 +35,13 @@ struct FlashP {
 };
 
 // CAUSAL is a template parameter: the spatial / cross-attention instantiations carry no trace of the mask
-template <int QB, bool CAUSAL>
+template <int QB, bool CAUSAL, bool VROW>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     // LDS: 2 stages x { K tile [64 key][64 d], V^T tile [64 d][64 key] }, 128-B rows,
-    // 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7)  (conflict-free for both reads)
+    // 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7)  (conflict-free for both reads).
+    // VROW: the second half of a stage is the V tile [64 key][64 d], chunk c of row r at c ^ (4 * ((r >> 1) & 1)):
+    // a transposed read takes 4 key rows x 32 d (64 B) per 32-lane half; rows r, r+1 are 128 B apart (other half of
+    // the 64 banks) and the XOR moves rows r+2, r+3 to the other 64 B of their lines: 32 lanes x 8 B on 64 banks once.
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
@@ -79,11 +84,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     const f16* zp = (const f16*)g_zero_page;
     const int st_row0 = tid >> 3, st_row1 = st_row0 + 32;             // K key / V^T d row of my piece 0 / 1
     const int ch0 = (tid & 7) ^ ((st_row0 >> 1) & 7), ch1 = (tid & 7) ^ ((st_row1 >> 1) & 7);
+    const int chv = (tid & 7) ^ (((st_row0 >> 1) & 1) << 2);           // VROW (st_row1 = st_row0 + 32: same swizzle)
     const f16* kptr0 = p.k + ((size_t)kvb * p.skv_pad + st_row0) * p.ldk + head * 64 + ch0 * 8;
     const f16* kptr1 = p.k + ((size_t)kvb * p.skv_pad + st_row1) * p.ldk + head * 64 + ch1 * 8;
-    const f16* vptr0 = p.vt + ((size_t)head * 64 + st_row0) * p.ldvt + (size_t)kvb * p.skv_pad + ch0 * 8;
-    const f16* vptr1 = p.vt + ((size_t)head * 64 + st_row1) * p.ldvt + (size_t)kvb * p.skv_pad + ch1 * 8;
-    const size_t kstep = (size_t)64 * p.ldk;
+    const f16* vptr0 = VROW ? p.vt + ((size_t)kvb * p.skv_pad + st_row0) * p.ldvt + head * 64 + chv * 8
+                            : p.vt + ((size_t)head * 64 + st_row0) * p.ldvt + (size_t)kvb * p.skv_pad + ch0 * 8;
+    const f16* vptr1 = VROW ? p.vt + ((size_t)kvb * p.skv_pad + st_row1) * p.ldvt + head * 64 + chv * 8
+                            : p.vt + ((size_t)head * 64 + st_row1) * p.ldvt + (size_t)kvb * p.skv_pad + ch1 * 8;
+    const size_t kstep = (size_t)64 * p.ldk, vstep = VROW ? (size_t)64 * p.ldvt : 64;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto issue = [&](int t, int buf) {
@@ -93,8 +101,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         if (k0 + 64 > p.skv_pad) {                                    // tile crosses skv_pad (wave-uniform)
             if (k0 + st_row0 >= p.skv_pad) k0p = zp;
             if (k0 + st_row1 >= p.skv_pad) k1p = zp;
-            if (k0 + ch0 * 8 >= p.skv_pad) v0p = zp;                  // chunks never straddle skv_pad
-            if (k0 + ch1 * 8 >= p.skv_pad) v1p = zp;
+            if (VROW) {
+                if (k0 + st_row0 >= p.skv_pad) v0p = zp;
+                if (k0 + st_row1 >= p.skv_pad) v1p = zp;
+            } else {
+                if (k0 + ch0 * 8 >= p.skv_pad) v0p = zp;              // chunks never straddle skv_pad
+                if (k0 + ch1 * 8 >= p.skv_pad) v1p = zp;
+            }
         }
         __builtin_amdgcn_global_load_lds((gptr_t)k0p, (lptr_t)sk, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)k1p, (lptr_t)(sk + 4096), 16, 0, 0);
@@ -102,8 +115,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         __builtin_amdgcn_global_load_lds((gptr_t)v1p, (lptr_t)(sk + 8192 + 4096), 16, 0, 0);
         kptr0 += kstep;
         kptr1 += kstep;
-        vptr0 += 64;
-        vptr1 += 64;
+        vptr0 += vstep;
+        vptr1 += vstep;
     };
 
     f32x16 o_acc[QB][2];
@@ -125,6 +138,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 
     bool offset_on = false;                // wave-uniform: some row of this wave has a non-zero offset
     const int krow = pi_row(r32);
+    // VROW: transposed-read address of this lane inside a V tile, for d block 0 / 1.  Lane 4q+p of a 16-lane group
+    // supplies row q, d columns 4p..4p+3 of a block of 4 keys x 16 d and receives column (lane & 15) of the 4 rows:
+    // group (lane >> 4) & 1 takes d 16..31 of the d block, lane half h keys 8h.. of the operand's 16.
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    const int tr0 = (8 * h + tq) * 128 + (((2 * tg + (tp >> 1)) ^ ((tq >> 1) << 2)) << 4) + 8 * (tp & 1);
+    const int tr1 = tr0 ^ 64;
     int ntiles = (p.skv + 63) >> 6;
     if (CAUSAL) ntiles = min(ntiles, ((qblk + 1) * 4 * 32 * QB + 63) >> 6);   // keys beyond the block's last query: all masked
     issue(0, 0);
@@ -245,8 +264,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
             const int c = 2 * kk + h;
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int row = db * 32 + r32;
-                const f16x8 vf = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                f16x8 vf;
+                if (VROW) {      // keys 16kk + 8h + (0..3 | 4..7) of d = 32db + (lane & 31)
+                    typedef short s16x4v __attribute__((__vector_size__(8)));
+                    typedef __attribute__((address_space(3))) s16x4v* ltr_t;
+                    struct TrPair { s16x4v lo, hi; } pr;
+                    const char* vb = Vs + (db ? tr1 : tr0) + kk * 2048;
+                    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)vb);
+                    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(vb + 512));
+                    vf = __builtin_bit_cast(f16x8, pr);
+                } else {
+                    const int row = db * 32 + r32;
+                    vf = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kk], o_acc[qb][db], 0, 0, 0);
@@ -290,12 +320,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     }
 }
 
-extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
-                                  void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
-                                  int seq_per_kv, float scale, int causal, vdx_stream_t stream) {
+template <bool VROW>
+static int flash_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                        void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
+                        int seq_per_kv, float scale, int causal, vdx_stream_t stream) {
     VDX_CHECK(q && k && vt && out, "flash_attn: null pointer");
     VDX_CHECK(n_seq > 0 && sq > 0 && skv > 0 && heads > 0 && seq_per_kv > 0, "flash_attn: empty problem");
-    VDX_CHECK(skv_pad >= skv && skv_pad % 8 == 0, "flash_attn: skv_pad=%d must be >= skv=%d and a multiple of 8", skv_pad, skv);
+    VDX_CHECK(skv_pad >= skv && (VROW || skv_pad % 8 == 0), "flash_attn: skv_pad=%d must be >= skv=%d%s", skv_pad, skv,
+              VROW ? "" : " and a multiple of 8");
     VDX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0, "flash_attn: leading dims must be multiples of 8");
     VDX_CHECK(n_seq % seq_per_kv == 0, "flash_attn: n_seq=%d not a multiple of seq_per_kv=%d", n_seq, seq_per_kv);
     VDX_CHECK(heads <= 65535 && n_seq <= 65535, "flash_attn: grid too large");
@@ -314,12 +346,24 @@ extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk
     VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
     if (two) {
         dim3 grid(p.nqb * p.npairs);
-        if (causal) hipLaunchKernelGGL((flash_attn_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((flash_attn_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (causal) hipLaunchKernelGGL((flash_attn_kernel<2, true, VROW>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<2, false, VROW>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
         dim3 grid(p.nqb * p.npairs);
-        if (causal) hipLaunchKernelGGL((flash_attn_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((flash_attn_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (causal) hipLaunchKernelGGL((flash_attn_kernel<1, true, VROW>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<1, false, VROW>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
-    return vdx_launch_status("vdx_flash_attn_f16");
+    return vdx_launch_status(VROW ? "vdx_flash_attn_rows_f16" : "vdx_flash_attn_f16");
+}
+
+extern "C" int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                  void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
+                                  int seq_per_kv, float scale, int causal, vdx_stream_t stream) {
+    return flash_launch<false>(q, ldq, k, ldk, vt, ldvt, out, ldo, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, causal, stream);
+}
+
+extern "C" int vdx_flash_attn_rows_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                                       void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
+                                       int seq_per_kv, float scale, int causal, vdx_stream_t stream) {
+    return flash_launch<true>(q, ldq, k, ldk, v, ldv, out, ldo, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, causal, stream);
 }

@@ -338,19 +338,22 @@ def rows_to_u8_frames(rows, n, H, W):
 
 
 # --------------------------------------------------------------------------------------------
-def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, out=None, causal=False):
-    """q rows [n_seq*sq][>=heads*64]; k rows [n_kv*skv_pad][>=heads*64]; vt [heads*64][>= n_kv*skv_pad]."""
+def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, out=None, causal=False, v_rows=False):
+    """q rows [n_seq*sq][>=heads*64]; k rows [n_kv*skv_pad][>=heads*64]; vt [heads*64][>= n_kv*skv_pad] — or, with
+    `v_rows`, V as rows like k (the third column block of a q|k|v projection: `vdx_flash_attn_rows_f16`)."""
     lib = _lib.load()
     qr, qc, ldq = _rows(q, "q")
     kr, kc, ldk = _rows(k, "k")
-    vr, vc, ldvt = _rows(vt, "vt")
+    vr, vc, ldvt = _rows(vt, "v" if v_rows else "vt")
     inner = heads * 64
     n_kv = n_seq // seq_per_kv
     if qr < n_seq * sq or qc < inner:
         raise VdxError("flash_attn: q too small")
     if kr < n_kv * skv_pad or kc < inner:
         raise VdxError("flash_attn: k too small")
-    if vr < inner or vc < n_kv * skv_pad:
+    if v_rows and (vr < n_kv * skv_pad or vc < inner):
+        raise VdxError("flash_attn: v too small")
+    if not v_rows and (vr < inner or vc < n_kv * skv_pad):
         raise VdxError("flash_attn: vt too small")
     if out is None:
         out = torch.empty((n_seq * sq, inner), dtype=torch.float16, device=q.device)
@@ -360,14 +363,15 @@ def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, o
     if PROFILE is not None:        # bench.py instrumentation (as in gemm): HIP events on the launch stream
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(lib.vdx_flash_attn_f16(_p(q, "q"), ldq, _p(k, "k"), ldk, _p(vt, "vt"), ldvt, _p(out, "out"), ldo,
-                                      n_seq, sq, skv, skv_pad, heads, seq_per_kv, float(scale), int(bool(causal)), _stream()),
-               "vdx_flash_attn_f16")
+    fn = lib.vdx_flash_attn_rows_f16 if v_rows else lib.vdx_flash_attn_f16
+    _lib.check(fn(_p(q, "q"), ldq, _p(k, "k"), ldk, _p(vt, "vt"), ldvt, _p(out, "out"), ldo,
+                  n_seq, sq, skv, skv_pad, heads, seq_per_kv, float(scale), int(bool(causal)), _stream()),
+               "vdx_flash_attn_rows_f16" if v_rows else "vdx_flash_attn_f16")
     if PROFILE is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         two = sq >= 512 and skv >= 256                      # flash.hip: 64 queries per wave
-        name = f"flash_attn_kernel<{2 if two else 1}, {'true' if causal else 'false'}>"
+        name = f"flash_attn_kernel<{2 if two else 1}, {'true' if causal else 'false'}, {'true' if v_rows else 'false'}>"
         PROFILE.append((name, 4.0 * n_seq * heads * sq * skv * 64, ev0, ev1, (n_seq * sq, skv, heads * 64)))
     return out
 

@@ -119,16 +119,13 @@ class UNet3DConditionModel(nn.Module):
             put(prefix + ".weight", get(prefix + ".weight"))
             put(prefix + ".bias", get(prefix + ".bias"))
 
-        def attn_self(prefix, fuse_v):
+        def attn_self(prefix, temporal):
+            # one [3*inner][inner] projection for both kinds (the spatial flash kernel takes V as rows: round 3)
             q, k, v = (packing.pack_conv1x1(get(f"{prefix}.to_{n}.weight")) for n in "qkv")
-            if fuse_v:      # temporal attention: one [3*inner][inner] projection
-                put(prefix + ".to_qkv.weight", torch.cat([q, k, v], 0))
-                if q.shape[0] in packing.K7_GEOMETRY and q.shape[0] not in packing.K7B_WIDTHS:      # widths only the first fused sub-block kernel (K7) is built for
-                    put(prefix + ".k7_qkv", packing.pack_k7_qkv(q, k, v))
-                    put(prefix + ".k7_out", packing.pack_k7_out(packing.pack_conv1x1(get(f"{prefix}.to_out.0.weight"))))
-            else:           # spatial self-attention: [q|k] fused, V issued as the swapped GEMM (-> V^T)
-                put(prefix + ".to_qk.weight", torch.cat([q, k], 0))
-                put(prefix + ".to_v.weight", v)
+            put(prefix + ".to_qkv.weight", torch.cat([q, k, v], 0))
+            if temporal and q.shape[0] in packing.K7_GEOMETRY and q.shape[0] not in packing.K7B_WIDTHS:      # widths only the first fused sub-block kernel (K7) is built for
+                put(prefix + ".k7_qkv", packing.pack_k7_qkv(q, k, v))
+                put(prefix + ".k7_out", packing.pack_k7_out(packing.pack_conv1x1(get(f"{prefix}.to_out.0.weight"))))
             lin(prefix + ".to_out.0")
 
         def attn_cross(prefix):
@@ -147,9 +144,9 @@ class UNet3DConditionModel(nn.Module):
             lin(prefix + ".proj_in")
             b = prefix + ".transformer_blocks.0"
             norm(b + ".norm1"); norm(b + ".norm2"); norm(b + ".norm3")
-            attn_self(b + ".attn1", fuse_v=temporal)
+            attn_self(b + ".attn1", temporal)
             if temporal:
-                attn_self(b + ".attn2", fuse_v=True)
+                attn_self(b + ".attn2", True)
             else:
                 attn_cross(b + ".attn2")
             ff(b + ".ff")
@@ -413,51 +410,30 @@ class UNet3DConditionModel(nn.Module):
                           rows_per_sample=S, eps=1e-6, silu_act=False)
         t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
         del n
-        # --- self-attention
-        Mp = ops.round_up(M, 64)
-        ln = torch.empty((Mp, C), dtype=torch.float16, device=x.device)
-        if Mp != M:
-            ln[M:].zero_()
-        ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M, out=ln)
-        if S % 8 == 0 and self.ff_block_bytes and self.lean_attn and S % 64 == 0 and n_img % 2 == 0 and M * C * 2 > (128 << 20):
-            # memory-lean mode: images are independent in the self-attention, so q|k, V^T and the attention run over
-            # the images in two halves and only half of those intermediates ([rows][2C] + [C][rows]) is alive at a time.
+        # --- self-attention: q | k | v from ONE projection; the flash kernel takes V as rows (transposed by its LDS read),
+        # so there is no V^T product and no padded copy for token counts that are no multiple of 8 (latent 40x72 ->
+        # 5x9 = 45 tokens at the mid block, InferNet/tests/test_pipeline.py:293; 16x16 -> 2x2 = 4, InferNet/neurons/miner.py:491-494)
+        ln = ops.layernorm(t, W[b + ".norm1.weight"], W[b + ".norm1.bias"], M=M)
+        wqkv = W[b + ".attn1.to_qkv.weight"]
+        if self.ff_block_bytes and self.lean_attn and n_img % 2 == 0 and M * C * 2 > (128 << 20):
+            # memory-lean mode: images are independent in the self-attention, so the projection and the attention run
+            # over the images in two halves and only half of [rows][3C] is alive at a time.
             # (level 0 only: 0.6 ms per step on a 16-frame window for 45 MB of its peak — measured 4.33 against 4.374 GB
             # with the concat pieces on, gpurun_out r3n — which is what keeps the per-device share under 15 %)
             o = torch.empty((M, C), dtype=torch.float16, device=x.device)
             hm, hn = M // 2, n_img // 2
             for r0 in (0, hm):
-                qk = ops.gemm(ln[r0:r0 + hm], W[b + ".attn1.to_qk.weight"], M=hm)
-                vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln[r0:r0 + hm], M=C)
-                ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=hn, sq=S, skv=S, skv_pad=S, heads=heads, seq_per_kv=1,
-                               scale=scale, out=o[r0:r0 + hm])
-                del qk, vt
+                qkv = ops.gemm(ln[r0:r0 + hm], wqkv, M=hm)
+                ops.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_seq=hn, sq=S, skv=S, skv_pad=S, heads=heads,
+                               seq_per_kv=1, scale=scale, out=o[r0:r0 + hm], v_rows=True)
+                del qkv
             del ln
-        elif S % 8 == 0:
-            qk = ops.gemm(ln, W[b + ".attn1.to_qk.weight"], M=M)
-            vt = ops.gemm(W[b + ".attn1.to_v.weight"], ln, M=C)                   # V^T [C][Mp]
-            del ln
-            o = ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_img, sq=S, skv=S, skv_pad=S, heads=heads,
-                               seq_per_kv=1, scale=scale)
-            del qk, vt
         else:
-            # Token counts that are no multiple of 8 (latent 40x72 -> 5x9 = 45 tokens at the mid block,
-            # InferNet/tests/test_pipeline.py:293; 16x16 -> 2x2 = 4, InferNet/neurons/miner.py:491-494): the
-            # attention kernel reads V^T in 16-byte chunks of 8 keys, so every image's keys start at a multiple
-            # of 8 — K and V^T are projected from a copy of the normalised rows laid out with S_pad rows per
-            # image (pad rows zero; the kernel masks keys >= S).  Only the smallest levels ever get here.
-            Sp = ops.round_up(S, 8)
-            Mk = n_img * Sp
-            lnp = torch.zeros((ops.round_up(Mk, 64), C), dtype=torch.float16, device=x.device)
-            lnp[:Mk].view(n_img, Sp, C)[:, :S] = ln[:M].view(n_img, S, C)
-            wqk = W[b + ".attn1.to_qk.weight"]
-            q = ops.gemm(ln, wqk[:C], M=M)
-            k = ops.gemm(lnp, wqk[C:], M=Mk)
-            vt = ops.gemm(W[b + ".attn1.to_v.weight"], lnp, M=C)                  # V^T [C][n_img*Sp (+pad)]
-            del ln, lnp
-            o = ops.flash_attn(q, k, vt, n_seq=n_img, sq=S, skv=S, skv_pad=Sp, heads=heads, seq_per_kv=1,
-                               scale=scale)
-            del q, k, vt
+            qkv = ops.gemm(ln, wqkv, M=M)
+            del ln
+            o = ops.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_seq=n_img, sq=S, skv=S, skv_pad=S, heads=heads,
+                               seq_per_kv=1, scale=scale, v_rows=True)
+            del qkv
         t = ops.gemm(o, W[b + ".attn1.to_out.0.weight"], M=M, bias=W[b + ".attn1.to_out.0.bias"], residual=t)
         del o
         # --- cross-attention over the (padded) text tokens; all F frames of a sample share K/V

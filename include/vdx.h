@@ -155,6 +155,13 @@ int vdx_layernorm_f16(const void* x, int ldx, const void* gamma, const void* bet
 int vdx_flash_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                        void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
                        int seq_per_kv, float scale, int causal, vdx_stream_t stream);
+/* The same with V as ROWS: v fp16 [n_kv*skv_pad][ldv], head h at columns h*64.. like k — q, k and v can then be the
+ * three column blocks of ONE projection's output (spatial self-attention of Transformer2DModel: no transposed V
+ * product).  The V tile is staged like K and transposed by the LDS read (ds_read_b64_tr_b16).  skv_pad >= skv, any
+ * value (a V^T row of 8-key chunks is what asks for a multiple of 8 above); rows skv..skv_pad-1 must hold finite values. */
+int vdx_flash_attn_rows_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                            void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
+                            int seq_per_kv, float scale, int causal, vdx_stream_t stream);
 
 /* Temporal self-attention of TransformerTemporalModel: sequences run over the
  * F frames of one latent pixel.  qkv: fp16 rows [B*F*HW][ldqkv] = [q | k | v] each heads*64

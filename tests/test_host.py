@@ -207,7 +207,8 @@ def test_gemm_plan_is_host_only_and_splits_the_mostly_idle_last_round():
     assert plan(73728, 640, 1920, mode=2, taps=3, frames=16, hw=2304) == (2, 65536)       # 2.25 rounds -> 2 + tail
     assert plan(73728, 640, 1920, mode=2, taps=3, frames=16, hw=2304, row_begin=65536) == (1, 0)   # the tail: 128x128
     assert plan(442368, 320, 960, mode=2, taps=3, frames=24, hw=9216) == (2, 0)           # 6.75 rounds: not worth it
-    assert plan(18432, 1280, 1280) == (1, 0)                                              # 16-frame level 2
+    assert plan(18432, 1280, 1280) == (1, 16384)      # 16-frame level 2: 1.125 rounds of big tiles -> one whole round + a small-tile tail
+    assert plan(18432, 1280, 1280, row_begin=16384) == (1, 0)
     assert plan(6912, 1280, 1280) == (8, 0)                                               # level 3
     assert plan(442368, 320, 320) == (7, 0)                                               # weights-stationary
     assert plan(442368, 320, 320, row_end=1024)[0] != 7                                   # ... whole products only

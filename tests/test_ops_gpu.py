@@ -469,6 +469,51 @@ def _attn_ref(q, k, v, heads):
     return o.transpose(1, 2).reshape(n * s, heads * 64)
 
 
+@pytest.mark.parametrize("n_seq,s,heads", [(3, 144, 2), (2, 64, 1), (2, 200, 3), (1, 576, 2), (1, 4096, 2), (5, 45, 2), (3, 4, 1),
+                                           (2, 2304, 3), (4, 67, 2)])
+def test_flash_self_attention_v_rows(gpu, n_seq, s, heads):
+    """q, k, v as the three column blocks of one [rows][3*inner] matrix (`vdx_flash_attn_rows_f16`: V staged as rows and
+    transposed by the LDS read).  Token counts that are no multiple of 8 (45 = the 40x72 latent's mid block, 4, 67)
+    need no padded copy in this layout: the next image's rows / the zero page stand behind a masked key."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(n_seq + s)
+    inner = heads * 64
+    M = n_seq * s
+    qkv = h(torch.randn(M, 3 * inner, generator=g))
+    q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    ref = _attn_ref(q.reshape(n_seq, s, inner), k.reshape(n_seq, s, inner), v.reshape(n_seq, s, inner), heads)
+    qkv_d = qkv.half().to(gpu)
+    out = ops.flash_attn(qkv_d[:, :inner], qkv_d[:, inner:2 * inner], qkv_d[:, 2 * inner:], n_seq=n_seq, sq=s, skv=s,
+                         skv_pad=s, heads=heads, seq_per_kv=1, scale=0.125, v_rows=True)
+    close(out, ref, tol=4e-3)
+    # bit-identical to the V^T form: same products in the same order, only the way V reaches the operand differs
+    Mp = ops.round_up(M, 64)
+    if s % 8 == 0:
+        vt = torch.zeros(inner, Mp, dtype=torch.float16, device=gpu)
+        vt[:, :M] = qkv_d[:, 2 * inner:].t()
+        out_t = ops.flash_attn(qkv_d[:, :inner], qkv_d[:, inner:2 * inner], vt, n_seq=n_seq, sq=s, skv=s, skv_pad=s,
+                               heads=heads, seq_per_kv=1, scale=0.125)
+        assert torch.equal(out, out_t)
+
+
+def test_flash_v_rows_last_rows_of_the_buffer(gpu):
+    """The last image's last tile reaches past the buffer's rows: those come from the zero page, never from memory
+    behind the allocation (the V rows sit at the very end of a caching-allocator block here; NaNs behind a masked
+    key would poison the sums)."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(77)
+    s, heads, n_seq = 100, 1, 2
+    big = torch.full((n_seq * s + 64, 192), float("nan"), dtype=torch.float16, device=gpu)
+    qkv = h(torch.randn(n_seq * s, 192, generator=g))
+    big[:n_seq * s] = qkv.half().to(gpu)
+    view = big[:n_seq * s]
+    ref = _attn_ref(qkv[:, :64].reshape(n_seq, s, 64), qkv[:, 64:128].reshape(n_seq, s, 64), qkv[:, 128:].reshape(n_seq, s, 64), heads)
+    out = ops.flash_attn(view[:, :64], view[:, 64:128], view[:, 128:], n_seq=n_seq, sq=s, skv=s, skv_pad=s, heads=heads,
+                         seq_per_kv=1, scale=0.125, v_rows=True)
+    assert bool(torch.isfinite(out.float()).all())
+    close(out, ref, tol=4e-3)
+
+
 @pytest.mark.parametrize("n_seq,s,heads", [(3, 144, 2), (2, 64, 1), (2, 200, 3), (1, 576, 2), (1, 4096, 2)])
 def test_flash_self_attention(gpu, n_seq, s, heads):
     ops, _ = _ops()
@@ -556,6 +601,9 @@ def test_flash_attention_lazy_offset_branches(gpu, case, s):
                          skv=s, skv_pad=s, heads=1, seq_per_kv=1, scale=0.125)
     assert bool(torch.isfinite(out.float()).all()), "flash attention produced non-finite values"
     close(out, ref, tol=4e-3)
+    out_r = ops.flash_attn(q.half().to(gpu), k.half().to(gpu), v.half().to(gpu), n_seq=1, sq=s, skv=s, skv_pad=s, heads=1,
+                           seq_per_kv=1, scale=0.125, v_rows=True)
+    assert torch.equal(out_r, out)
 
 
 @pytest.mark.parametrize("B,Fr,s,heads,skv", [(2, 3, 144, 2, 77), (1, 4, 64, 1, 77), (2, 2, 100, 2, 5)])
@@ -576,6 +624,12 @@ def test_flash_cross_attention(gpu, B, Fr, s, heads, skv):
     out = ops.flash_attn(q.reshape(-1, inner).half().to(gpu), kd, vt, n_seq=B * Fr, sq=s, skv=skv, skv_pad=skv_pad,
                          heads=heads, seq_per_kv=Fr, scale=0.125)
     close(out, ref, tol=4e-3)
+    vd = torch.zeros(B * skv_pad, inner, dtype=torch.float16, device=gpu)
+    for b in range(B):
+        vd[b * skv_pad:b * skv_pad + skv] = v[b].half().to(gpu)
+    out_r = ops.flash_attn(q.reshape(-1, inner).half().to(gpu), kd, vd, n_seq=B * Fr, sq=s, skv=skv, skv_pad=skv_pad,
+                           heads=heads, seq_per_kv=Fr, scale=0.125, v_rows=True)
+    assert torch.equal(out_r, out)
 
 
 @pytest.mark.parametrize("B,Fr,HW,heads", [(2, 5, 7, 2), (1, 24, 12, 5), (2, 32, 3, 1), (1, 1, 9, 2), (2, 16, 130, 8),

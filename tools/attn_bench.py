@@ -37,7 +37,26 @@ for lvl, (hw, C) in enumerate([(9216, 320), (2304, 640), (576, 1280), (144, 1280
     ms = timeit(lambda: ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_seq, sq=hw, skv=hw, skv_pad=hw, heads=heads,
                                        seq_per_kv=1, scale=0.125, out=out))
     fl = 4.0 * n_seq * heads * hw * hw * 64
-    print(f"L{lvl} self-attn  S={hw:5d} heads={heads:2d}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
+    print(f"L{lvl} self-attn  S={hw:5d} heads={heads:2d}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  (V^T operand)")
+    # V as rows of one q|k|v matrix (what the UNet runs since round 3), and the whole chain either way
+    qkv = rnd(M, 3 * C)
+    msr = timeit(lambda: ops.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_seq=n_seq, sq=hw, skv=hw, skv_pad=hw,
+                                        heads=heads, seq_per_kv=1, scale=0.125, out=out, v_rows=True))
+    print(f"L{lvl} self-attn  V as rows        : {msr:8.3f} ms  {fl / msr / 1e9:7.1f} TFLOP/s")
+    ln, w3 = rnd(M, C), rnd(3 * C, C) * 0.05
+
+    def chain_t():
+        a = ops.gemm(ln, w3[:2 * C], M=M)
+        b_ = ops.gemm(w3[2 * C:], ln, M=C)
+        ops.flash_attn(a[:, :C], a[:, C:], b_, n_seq=n_seq, sq=hw, skv=hw, skv_pad=hw, heads=heads, seq_per_kv=1, scale=0.125, out=out)
+
+    def chain_r():
+        a = ops.gemm(ln, w3, M=M)
+        ops.flash_attn(a[:, :C], a[:, C:2 * C], a[:, 2 * C:], n_seq=n_seq, sq=hw, skv=hw, skv_pad=hw, heads=heads, seq_per_kv=1,
+                       scale=0.125, out=out, v_rows=True)
+    mt, mr = timeit(chain_t), timeit(chain_r)
+    print(f"L{lvl} projection + attention      : q|k GEMM + V^T GEMM + flash {mt:8.3f} ms   q|k|v GEMM + flash(rows) {mr:8.3f} ms")
+    del qkv, ln, w3
     # peaked attention (q, k x4: scores ~ N(0, 16 nat), row maxima ~ +60 nat): the lazy softmax offset has to
     # move — the uniform-attention figure above is the never-moves best case
     qk4 = qk * 4
