@@ -76,6 +76,7 @@ class UNet3DConditionModel(nn.Module):
         self.ff_block_bytes = None     # memory-lean feed-forward (see _ff); shard_() turns it on
         self.lean_concat = True        # (with ff_block_bytes set) concat GroupNorm -> conv1 over pieces of whole frames
         self.lean_attn = True          # (with ff_block_bytes set) spatial self-attention over image halves
+        self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
         self._text_ref = None                  # (encoder_hidden_states object, its version, (B, device), padded copy)
         self._text_kv: Dict[str, tuple] = {}   # cross-attention K / V^T of that text, per transformer
@@ -428,6 +429,13 @@ class UNet3DConditionModel(nn.Module):
                                seq_per_kv=1, scale=scale, out=o[r0:r0 + hm], v_rows=True)
                 del qkv
             del ln
+        elif not self.spatial_v_rows and S % 8 == 0 and M % 64 == 0:
+            # the round-2 form, kept for same-process A/B timing (tools/step_ab.py): q|k GEMM + V^T by the swapped GEMM
+            qk = ops.gemm(ln, wqkv[:2 * C], M=M)
+            vt = ops.gemm(wqkv[2 * C:], ln, M=C)
+            del ln
+            o = ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_img, sq=S, skv=S, skv_pad=S, heads=heads, seq_per_kv=1, scale=scale)
+            del qk, vt
         else:
             qkv = ops.gemm(ln, wqkv, M=M)
             del ln
