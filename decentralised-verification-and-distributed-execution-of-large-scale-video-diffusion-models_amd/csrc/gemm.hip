@@ -46,7 +46,7 @@ extern "C" int vdx_debug_read_stamps(void* dst, int nblocks) {
 // their two K halves while the activation waves run MFMAs.  The weights are L2-resident (0.2-0.4 us to
 // land), so half a K tile of lead is enough for them; the activation rows, which may come from HBM, keep
 // the full K tile of lead.
-template <int BM, int BN, int NT, int MODE, bool SPLIT>
+template <int BM, int BN, int NT, int MODE, bool SPLIT, bool UPS2 = false>
 struct Stager {
     static constexpr int IT = SPLIT ? NT / 2 : NT;        // issue slots per operand
     static constexpr int RPP = IT / 8;                    // LDS rows covered by one DMA instruction of all slots
@@ -112,12 +112,12 @@ struct Stager {
             for (int i = 0; i < ACH; ++i) {
                 int y = (d1[i] >> 16) + ky - 1, x = (d1[i] & 0xffff) + kx - 1;
                 const bool ok = (unsigned)y < (unsigned)hlim && (unsigned)x < (unsigned)wlim;
-                if (p.ups == 1) {
-                    y >>= 1;
-                    x >>= 1;
-                } else if (p.ups == 2) {      // explicit target size (latent not divisible by 8): F.interpolate(size=, "nearest")
+                if (UPS2) {                   // explicit target size (latent not divisible by 8): F.interpolate(size=, "nearest")
                     y = min((int)((float)y * p.usy), p.h_in - 1);
                     x = min((int)((float)x * p.usx), p.w_in - 1);
+                } else {                      // (its own instantiation: the float index math costs the issue-bound K loop 11 %)
+                    y >>= p.ups;
+                    x >>= p.ups;
                 }
                 const f16* src = p.a + (size_t)(d0[i] + y * p.w_in + x) * p.lda + kc + csw;
                 __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * RPP * 128), 16, 0, 0);
@@ -158,12 +158,17 @@ struct Stager {
     }
 };
 
-template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT>
+// VAR: 0 the product kernels | 1 a split-K slice (p.ksplit > 1) | 2 the 3x3 gather with nearest-to-size upsampling.
+// (Variants 1 and 2 are their own instantiations so that the kernels of every ordinary step stay exactly the round-2
+// code: run-time `ksplit` / `ups == 2` branches in the one template cost the 3x3-conv kernel 11 % — 894 -> 995 us per
+// launch in the XL step, profiles/r03_kernel_stats.csv history.)
+template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT, int VAR>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    typedef Stager<BM, BN, NT, MODE, SPLIT> Stage;
+    constexpr bool KS = VAR == 1;
+    typedef Stager<BM, BN, NT, MODE, SPLIT, VAR == 2> Stage;
     constexpr int STAGE = Stage::STAGE;
     static_assert(TN % 2 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     // split-K (p.ksplit > 1): block = (tile, slice); the slices of a tile are neighbours, so they share an XCD's L2
     int kt_lo = 0, kt_hi = nk, slab = 0;
-    if (p.ksplit > 1) {
+    if (KS) {
         slab = bid;
         const int sl = bid % p.ksplit;
         bid /= p.ksplit;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     if (GEGLU) gelu_tab_init(gelu, tid, NT);
     Stage sg;
     sg.setup(p, tid, m0, n0);
-    if (kt_lo) sg.seek(kt_lo);
+    if (KS && kt_lo) sg.seek(kt_lo);
     if (does_w) sg.issue_w(p, smem, 0);
     if (does_a) sg.issue_a(p, smem, 0);
     sg.advance();
@@ -209,9 +214,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();                      // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
     STAMP(1);
-    for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        const int cur = (kt - kt_lo) & 1;
-        const bool more = kt + 1 < kt_hi;
+    for (int kt = KS ? kt_lo : 0; kt < (KS ? kt_hi : nk); ++kt) {
+        const int cur = KS ? (kt - kt_lo) & 1 : kt & 1;
+        const bool more = kt + 1 < (KS ? kt_hi : nk);
 #if !(defined(VDX_STAMPS) && VDX_ABL == 2)   // diagnostic ablation 2: no DMA inside the K loop
         // buffer cur^1 was last read before the previous barrier
 #if !(defined(VDX_STAMPS) && VDX_ABL == 5)    // ablation 5: no activation DMA in the loop
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     }
 
     STAMP(2);
-    if (p.ksplit > 1) {
+    if (KS) {
         // this slice's fp32 accumulators -> its slab, in register order ([accumulator][thread][4]: 16-byte coalesced
         // stores); vdx_gemm_reduce_kernel adds the slabs of a tile in slice order and runs the epilogue
         float* dst = p.partial + (size_t)slab * (NT * TM * TN * 4) + tid * 4;
@@ -288,10 +293,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
 }
 
 // ---- host side ------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool SPLIT = false, int VAR = 0>
 static int launch(const GemmP& p, hipStream_t st) {
     constexpr int lds = 2 * (BM + BN) * 128 + (GEGLU ? GELU_TAB_BYTES : 0);
-    auto kern = gemm_kernel<BM, BN, WM, WN, MODE, GEGLU, SPLIT>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, MODE, GEGLU, SPLIT, VAR>;
     // one-time LDS opt-in; a function-local static is initialised exactly once even under concurrent callers
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
@@ -343,7 +348,7 @@ template <int MODE>
 static int launch_ksplit(const GemmP& p, int ksplit, float* ws, hipStream_t st) {
     constexpr int BM = 256, BN = 320, WM = 4, WN = 2;
     constexpr int lds = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<BM, BN, WM, WN, MODE, false, MODE != 0>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, MODE, false, MODE != 0, 1>;
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr_rc != hipSuccess) return vdx_fail("gemm: cannot reserve %d bytes of LDS", lds);
     GemmP q = p;
@@ -411,6 +416,10 @@ static int choose_split(int begin, int end, int N) {
 template <int MODE, bool GEGLU>
 static int pick_tile(const GemmP& p, int force, hipStream_t st) {
     const int v = force ? force : choose_tile(p.M - p.m_begin, p.N).v;
+    if constexpr (MODE == 1 && !GEGLU) {
+        if (p.ups == 2)     // nearest-to-size gather: two instantiations of its own (latents not divisible by 8 only)
+            return v == 1 ? launch<128, 128, 2, 2, 1, false, false, 2>(p, st) : launch<256, 320, 4, 2, 1, false, true, 2>(p, st);
+    }
     switch (v) {
         case 1: return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
         case 2: return launch<256, 320, 4, 2, MODE, GEGLU, MODE != 0>(p, st);   // split roles pay on the gathers only
@@ -445,7 +454,7 @@ static int gemm_prepare(const vdx_gemm_args* a, GemmP& p, bool& geglu, int& forc
     p.M = a->row_end ? a->row_end : a->M; p.m_begin = a->row_begin; p.N = a->N; p.K = a->K; p.c1 = a->c1; p.c2 = a->c2;
     p.lda = a->lda; p.lda2 = a->lda2; p.ldo = a->ldo; p.ldr = a->ldr;
     p.h_in = a->h_in; p.w_in = a->w_in; p.h_out = a->h_out; p.w_out = a->w_out;
-    p.stride = a->stride; p.ups = a->upsample;
+    p.stride = a->stride; p.ups = a->upsample;     // (the gathers shift by ups: 0 | 1; ups == 2 runs the VAR = 2 kernels)
     p.h_up = a->upsample == 1 ? 2 * a->h_in : a->upsample == 2 ? a->h_out : a->h_in;
     p.w_up = a->upsample == 1 ? 2 * a->w_in : a->upsample == 2 ? a->w_out : a->w_in;
     p.usy = a->h_in > 0 && p.h_up > 0 ? (float)a->h_in / (float)p.h_up : 1.0f;

@@ -122,13 +122,8 @@ __global__ __launch_bounds__(WMB * 128) void gemm_ring_kernel(const GemmP p) {
             for (int i = 0; i < NA; ++i) {
                 int y = a_y[i] + ky, x = a_x[i] + kx;
                 const bool ok = a_ok[i] && (unsigned)y < (unsigned)hlim && (unsigned)x < (unsigned)wlim;
-                if (p.ups == 1) {
-                    y >>= 1;
-                    x >>= 1;
-                } else if (p.ups == 2) {      // explicit target size (latent not divisible by 8): F.interpolate(size=, "nearest")
-                    y = min((int)((float)y * p.usy), p.h_in - 1);
-                    x = min((int)((float)x * p.usx), p.w_in - 1);
-                }
+                y >>= p.ups;                  // 0 | 1 (nearest-to-size, ups == 2, runs the tiled kernels' own instantiation: gemm.hip pick_tile)
+                x >>= p.ups;
                 const f16* src = p.a + (a_off[i] + (size_t)(y * p.w_in + x)) * p.lda + kc + csw;
                 __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src : zp), (lptr_t)(sa + i * NW * 1024), 16, 0, 0);
             }

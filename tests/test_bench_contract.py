@@ -29,7 +29,7 @@ def test_pmc_traffic_is_reported_only_for_the_build_that_was_profiled(tmp_path, 
     import bench
     import vdx  # noqa: F401
     from vdx._lib import source_sha
-    k = "gemm_kernel<256, 320, 4, 2, 1, false, true>"
+    k = "gemm_kernel<256, 320, 4, 2, 1, false, true, 0>"
     prof = {k: {"launches": 70, "hbm_read_bytes_per_launch": 6.0e8, "hbm_write_bytes_per_launch": 1.7e8, "mfma_busy": 0.5},
             "_meta": {"source_sha": source_sha(), "forwards": 2, "hbm_bytes_all_kernels": 8.0e11, "kernels": [k]}}
     f = tmp_path / "pmc.json"
