@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: same-process A/B of model switches on the XL step (boxes of the pool differ by +-4 %, so only pairs measured
-in one process mean anything).  Usage: step_ab.py [frames] attr=a,b [attr=a,b ...]   e.g.  step_ab.py 24 spatial_v_rows=1,0"""
+in one process mean anything).  Usage: step_ab.py [frames] attr=a,b [attr=a,b ...]   e.g.  step_ab.py 24 spatial_v_rows=1,0 ff_block_bytes=0,134217728
+(bool attributes take 0 / 1; others take integers, 0 = None)"""
 import os
 import sys
 
@@ -32,14 +33,18 @@ def step_ms(n=3):
 
 
 for name, vals in switches:
-    vals = [int(v) for v in vals.split(",")]
+    cast = (lambda v: bool(int(v))) if isinstance(getattr(model, name), bool) else (lambda v: int(v) or None)
+    vals = [cast(v) for v in vals.split(",")]
+    if len(vals) == 1:          # a setting for the comparisons that follow
+        setattr(model, name, vals[0])
+        continue
     res = {v: [] for v in vals}
     for v in vals:
-        setattr(model, name, bool(v))
+        setattr(model, name, v)
         step_ms(1)
     for _ in range(5):
         for v in vals:
-            setattr(model, name, bool(v))
+            setattr(model, name, v)
             res[v].append(step_ms())
     print(f"{frames} frames, {name}: " + "   ".join(f"{v}: {sorted(r)[len(r) // 2]:.2f} ms (min {min(r):.2f})" for v, r in res.items()), flush=True)
-    setattr(model, name, bool(vals[0]))
+    setattr(model, name, vals[0])
