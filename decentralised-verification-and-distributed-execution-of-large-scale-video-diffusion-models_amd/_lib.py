@@ -52,6 +52,9 @@ SIGNATURES = {
     "vdx_timestep_embedding_f16": (_i, [_vp, _vp, _i, _i, _vp]),
     "vdx_gelu_f16": (_i, [_vp, _vp, _sz, _vp]),
     "vdx_temporal_attn_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "vdx_ff_block_supported": (_i, [_i]),
+    "vdx_ff_block_pack_bytes": (_sz, [_i]),
+    "vdx_ff_block_f16": (_i, [_vp, _i, _vp, _f, _vp, _i, _i, _i, _vp]),
     "vdx_temporal_attn_block_supported": (_i, [_i, _i]),
     "vdx_temporal_attn_block_wqkv_bytes": (_sz, [_i]),
     "vdx_temporal_attn_block_wo_bytes": (_sz, [_i]),

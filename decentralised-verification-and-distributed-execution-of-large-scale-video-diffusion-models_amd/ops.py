@@ -422,6 +422,40 @@ def temporal_attn_block2(t, packed, *, B, F, HW, eps=1e-5, out=None):
     return out
 
 
+def ff_block_supported(inner: int) -> bool:
+    return bool(_lib.load().vdx_ff_block_supported(inner))
+
+
+def ff_block(t, packed, *, M, eps=1e-5, out=None):
+    """K8 (csrc/ff_fused.hip): t + ff(LayerNorm(t)) — GEGLU feed-forward of a transformer block — in one kernel;
+    LayerNorm's affine and the biases are inside `packed` (packing.pack_k8)."""
+    lib = _lib.load()
+    r, inner, ldt = _rows(t, "t")
+    if r < M:
+        raise VdxError(f"ff_block: t has {r} rows, need {M}")
+    if not lib.vdx_ff_block_supported(inner):
+        raise VdxError(f"ff_block: inner={inner} not supported by the fused kernel")
+    if packed.dtype != torch.float16 or packed.numel() * 2 != lib.vdx_ff_block_pack_bytes(inner) or not packed.is_contiguous():
+        raise VdxError("ff_block: packed blob does not match the kernel's layout (packing.pack_k8)")
+    if out is None:
+        out = torch.empty((M, inner), dtype=torch.float16, device=t.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < inner:
+        raise VdxError("ff_block: out too small")
+    if out.data_ptr() == t.data_ptr():
+        raise VdxError("ff_block: out may not alias t")
+    if PROFILE is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(lib.vdx_ff_block_f16(_p(t, "t"), ldt, _p(packed, "packed"), float(eps), _p(out, "out"), ldo, M, inner, _stream()),
+               "vdx_ff_block_f16")
+    if PROFILE is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        PROFILE.append((f"ff_fused_kernel<{inner}>", 2.0 * M * inner * 12 * inner, ev0, ev1, (M, inner, 12 * inner)))
+    return out
+
+
 def temporal_attn_block_supported(inner: int, F: int) -> bool:
     return bool(_lib.load().vdx_temporal_attn_block_supported(inner, F))
 

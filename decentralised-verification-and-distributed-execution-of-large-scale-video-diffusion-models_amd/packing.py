@@ -210,3 +210,53 @@ def pack_k7b(wq, wk, wv, wo, gamma, beta, bo, scale: float) -> torch.Tensor:
     parts.append(_k7_slot_swizzle(u).reshape(-1))                               # [h][tile 4*kk + jt][16][4][8]
     vec = torch.cat([bq, bo2]).contiguous().view(torch.float16)
     return torch.cat([qkv] + parts + [vec]).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# K8 (csrc/ff_fused.hip): the feed-forward sub-block in one kernel.  LayerNorm's affine is folded into the first
+# projection: W1' = W1.diag(gamma), b1' = b1 + W1.beta (the initial accumulators of val / gate).  The hidden width is
+# cut into chunks of 64; a chunk's blob is 15 units of 8 KB in K7B's unit format: (val, gate) for each of the five K-64
+# steps, then the chunk's k slice of W2 — 2 + 2 units for the two 128-column groups, 1 for the last 64 columns — with
+# the k index permuted to the order in which val * gelu(gate) leaves the accumulators (as K7B's W_o).
+# ---------------------------------------------------------------------------------------------
+K8_WIDTHS = (320,)
+
+
+def pack_k8(w1, b1, w2, b2, gamma, beta) -> torch.Tensor:
+    """w1 [8*inner][inner] (rows: val | gate, diffusers GEGLU.proj), b1 [8*inner], w2 [inner][4*inner], b2 [inner]
+    -> fp16 tensor holding the blob (the fp32 vectors at its end are stored as raw bits)."""
+    inner = w2.shape[0]
+    assert inner in K8_WIDTHS and inner % 128 == 64
+    hid, km = 4 * inner, inner // 64
+    chunks = hid // 64
+    dev = w1.device
+    f = lambda x: x.to(device=dev, dtype=torch.float32)    # noqa: E731
+    w1, b1, w2, b2, gamma, beta = (f(x) for x in (w1, b1, w2, b2, gamma, beta))
+    val16 = (w1[:hid] * gamma[None, :]).half()
+    gate16 = (w1[hid:] * gamma[None, :]).half()
+    b1f = b1 + w1 @ beta
+    uv, ug = _k7b_units(val16, chunks, km), _k7b_units(gate16, chunks, km)     # [chunk][km][8][16][4][8]
+    a_units = torch.stack([uv, ug], dim=2).reshape(chunks, 2 * km, 8, 16, 4, 8)
+    w2h = w2.half()
+    ar = lambda n: torch.arange(n, device=dev)             # noqa: E731
+    q, j8 = ar(4)[:, None], ar(8)[None, :]
+    kperm = 16 * (j8 >> 2) + 4 * q + (j8 & 3)                                   # [4][8] hidden index inside a 32-wide k step
+    n = ar(16)
+
+    def cols(base, ntile):
+        jt = ar(ntile)[:, None]
+        return base + 32 * (jt // 2) + 8 * (n[None, :] >> 2) + 4 * (jt % 2) + (n[None, :] & 3)     # [ntile][16]
+
+    hcol = 64 * ar(chunks)[:, None, None, None] + 32 * ar(2)[None, :, None, None] + kperm[None, None]      # [chunk][kk][4][8]
+    b_units = []
+    for cg in range(inner // 128):
+        col = cols(128 * cg, 8)                                                 # [8][16]
+        u = w2h[col[None, None, :, :, None, None], hcol[:, :, None, None]]      # [chunk][kk][8][16][4][8]
+        b_units.append(u)
+    col = cols(128 * (inner // 128), 4)                                         # [4][16]
+    u = w2h[col[None, None, :, :, None, None], hcol[:, :, None, None]]          # [chunk][kk][4][16][4][8]
+    b_units.append(u.reshape(chunks, 1, 8, 16, 4, 8))                           # tile 4*kk + jt
+    units = torch.cat([a_units] + b_units, dim=1)                               # [chunk][15][8][16][4][8]
+    blob = _k7_slot_swizzle(units).reshape(-1)
+    bias = torch.cat([torch.stack([b1f[:hid].reshape(chunks, 64), b1f[hid:].reshape(chunks, 64)], dim=1).reshape(-1), b2])
+    return torch.cat([blob, bias.contiguous().view(torch.float16)]).contiguous()

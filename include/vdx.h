@@ -163,6 +163,17 @@ int vdx_flash_attn_rows_f16(const void* q, int ldq, const void* k, int ldk, cons
                             void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
                             int seq_per_kv, float scale, int causal, vdx_stream_t stream);
 
+/* K8 — the feed-forward sub-block of BasicTransformerBlock (`t = t + ff(norm3(t))`, GEGLU with the
+ * erf GELU, both in Transformer2DModel and TransformerTemporalModel) as ONE kernel: LayerNorm -> [val | gate] projection ->
+ * val * gelu(gate) -> output projection (+bias) + residual; the [rows][4*inner] intermediate never leaves the CU
+ * (csrc/ff_fused.hip).  Built for inner 320 (level 0).
+ *   t, out : fp16 rows [M][ld], `inner` columns used; out may not alias t
+ *   packed : vdx/packing.py pack_k8 (LayerNorm's affine folded into the first projection), vdx_ff_block_pack_bytes bytes */
+int vdx_ff_block_supported(int inner);
+size_t vdx_ff_block_pack_bytes(int inner);
+int vdx_ff_block_f16(const void* t, int ldt, const void* packed, float eps, void* out, int ldo, int M, int inner,
+                     vdx_stream_t stream);
+
 /* Temporal self-attention of TransformerTemporalModel: sequences run over the
  * F frames of one latent pixel.  qkv: fp16 rows [B*F*HW][ldqkv] = [q | k | v] each heads*64
  * wide, row = (b*F + f)*HW + p.  out rows likewise, [ldo] wide.  F <= 128.                     */

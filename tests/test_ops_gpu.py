@@ -916,3 +916,55 @@ def test_blend_bit_exact(gpu):
         ops.blend_accumulate(full, weight, lat.to(gpu), w.to(gpu), s, e)
     got = ops.blend_finalize(full, weight)
     assert torch.equal(got.cpu(), want)
+
+
+# ---------------------------------------------------------------------------------------------
+def _ff_ref(t, gamma, beta, w1, b1, w2, b2):
+    """fp32 statement of `t + ff(norm3(t))` of BasicTransformerBlock (GEGLU, erf GELU)."""
+    inner = t.shape[1]
+    ln = F.layer_norm(t, (inner,), gamma, beta, 1e-5)
+    pr = ln @ w1.t() + b1
+    val, gate = pr.chunk(2, dim=1)
+    return t + (val * F.gelu(gate)) @ w2.t() + b2
+
+
+@pytest.mark.parametrize("M", [192, 1000, 64 * 1024 + 5, 7])
+def test_ff_block_fused(gpu, M):
+    """K8 against the fp32 statement and against the un-fused chain it replaces (LayerNorm, GEGLU GEMM, GEMM + residual)."""
+    ops, _ = _ops()
+    from vdx import packing
+    g = torch.Generator().manual_seed(M)
+    inner = 320
+    t = h(torch.randn(M, inner, generator=g) * 1.5 + 0.3)
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    w1, b1 = h(torch.randn(8 * inner, inner, generator=g) * 0.06), h(torch.randn(8 * inner, generator=g) * 0.1)
+    w2, b2 = h(torch.randn(inner, 4 * inner, generator=g) * 0.03), h(torch.randn(inner, generator=g) * 0.1)
+    ref = _ff_ref(t, gamma, beta, w1, b1, w2, b2)
+    blob = packing.pack_k8(w1.to(gpu), b1.to(gpu), w2.to(gpu), b2.to(gpu), gamma.to(gpu), beta.to(gpu))
+    td = t.half().to(gpu)
+    out = ops.ff_block(td, blob, M=M)
+    close(out, ref, tol=4e-3)
+    # the un-fused chain on the same inputs
+    wp, bp = packing.pack_geglu(w1.half().to(gpu), b1.half().to(gpu))
+    ln = ops.layernorm(td, gamma.half().to(gpu), beta.half().to(gpu), M=M)
+    gg = ops.gemm(ln, wp, M=M, bias=bp, geglu=True)
+    un = ops.gemm(gg, packing.pack_conv1x1(w2.half().to(gpu)), M=M, bias=b2.half().to(gpu), residual=td)
+    close(out, un.float().cpu(), tol=4e-3)
+
+
+def test_ff_block_large_mean_and_outliers(gpu):
+    """Rows with a large common offset (LayerNorm statistics) and gate values far outside the polynomial's interval."""
+    ops, _ = _ops()
+    from vdx import packing
+    g = torch.Generator().manual_seed(5)
+    inner, M = 320, 777
+    t = h(torch.randn(M, inner, generator=g) * 0.5 + 40.0)
+    t[::7] = h(torch.randn((M + 6) // 7, inner, generator=g) * 30.0)
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    w1, b1 = h(torch.randn(8 * inner, inner, generator=g) * 0.3), h(torch.randn(8 * inner, generator=g) * 2.0)
+    w2, b2 = h(torch.randn(inner, 4 * inner, generator=g) * 0.01), h(torch.randn(inner, generator=g) * 0.1)
+    ref = _ff_ref(t, gamma, beta, w1, b1, w2, b2)
+    blob = packing.pack_k8(w1.to(gpu), b1.to(gpu), w2.to(gpu), b2.to(gpu), gamma.to(gpu), beta.to(gpu))
+    out = ops.ff_block(t.half().to(gpu), blob, M=M)
+    assert bool(torch.isfinite(out.float()).all())
+    close(out, ref, tol=6e-3)
