@@ -144,6 +144,9 @@ struct K8 {
     // ---- weight stream: unit U of the running chunk (U >= UPC: of the next chunk)
     template <int U>
     __device__ __forceinline__ void issue_unit() {
+#ifdef K8_ABL_NOWDMA       /* diagnostic builds (timing only, wrong results): what each part of the tile costs */
+        return;
+#endif
         const char* src = (U >= UPC ? wc1 + (size_t)(U - UPC) * UB : wc0 + (size_t)U * UB) + (2 * wave) * 1024 + lane * 16;
         char* dst = smem + XB + (U % NU) * UB + (2 * wave) * 1024;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
@@ -279,6 +282,15 @@ struct K8 {
     // val * gelu(gate) of the chunk -> the B operand of its output product.  Registers e of tile j: hidden 16*j + 4*q4 + e;
     // two tiles side by side are one operand (W2's k index is permuted to match: packing.pack_k8).
     __device__ __forceinline__ void geglu(State& st) {
+#ifdef K8_ABL_NOGEGLU
+        for (int i = 0; i < 3; ++i)
+            for (int kk = 0; kk < 2; ++kk)
+                for (int e = 0; e < 4; ++e) {
+                    st.hh[i][kk][e] = (f16)(st.av[i][2 * kk][e] + st.ag[i][2 * kk][e]);
+                    st.hh[i][kk][4 + e] = (f16)(st.av[i][2 * kk + 1][e] + st.ag[i][2 * kk + 1][e]);
+                }
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -402,9 +414,15 @@ struct K8 {
             asm volatile("" : "+s"(wave));
             set_lane_constants();
             set_row_pointers(st, tile);
+#ifdef K8_ABL_NOSEAM
+            if (tile == (int)blockIdx.x) {
+#endif
             init_acc(st);
             wait_vm<0>();
             rows_norm(std::make_integer_sequence<int, NPS>{});
+#ifdef K8_ABL_NOSEAM
+            }
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wg_barrier();                        // (first tile: the first units have landed for everyone)
             read_half<0, 0>(st.fa);
@@ -418,6 +436,11 @@ struct K8 {
                 steps(st, std::make_integer_sequence<int, CSTEPS>{});
             }
             const int next = tile + gridDim.x;
+#ifdef K8_ABL_NOSEAM
+            if (next >= p.ntiles) { epilogue(st); break; }
+            tile = next;
+            continue;
+#endif
             rows_in(next, std::make_integer_sequence<int, NPS>{});     // (the image is dead; past the last tile: the zero page)
             epilogue(st);
             if (next >= p.ntiles) break;

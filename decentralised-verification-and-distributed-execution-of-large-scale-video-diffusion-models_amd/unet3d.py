@@ -76,6 +76,7 @@ class UNet3DConditionModel(nn.Module):
         self.ff_block_bytes = None     # memory-lean feed-forward (see _ff); shard_() turns it on
         self.lean_concat = True        # (with ff_block_bytes set) concat GroupNorm -> conv1 over pieces of whole frames
         self.lean_attn = True          # (with ff_block_bytes set) spatial self-attention over image halves
+        self.fuse_ff = True            # K8 where the width allows (False: LayerNorm, GEGLU GEMM, GEMM + residual)
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
         self._text_ref = None                  # (encoder_hidden_states object, its version, (B, device), padded copy)
@@ -152,6 +153,10 @@ class UNet3DConditionModel(nn.Module):
                 attn_cross(b + ".attn2")
             ff(b + ".ff")
             lin(prefix + ".proj_out")
+            if sd[b + ".ff.net.2.weight"].shape[0] in packing.K8_WIDTHS:
+                # K8: the feed-forward sub-block as one kernel, norm3 folded into its first projection (csrc/ff_fused.hip)
+                put(b + ".ff.k8", packing.pack_k8(sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"], sd[b + ".ff.net.2.weight"],
+                                                 sd[b + ".ff.net.2.bias"], sd[b + ".norm3.weight"], sd[b + ".norm3.bias"]))
             if temporal and sd[b + ".attn1.to_q.weight"].shape[0] in packing.K7B_WIDTHS:
                 # K7, second design: one blob per attention sub-block with its LayerNorm folded in (csrc/tattn2.hip)
                 for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
@@ -372,6 +377,10 @@ class UNet3DConditionModel(nn.Module):
     def _ff(self, b, t, M):
         W = self.W
         inner = t.shape[1]
+        if self.fuse_ff and b + ".ff.k8" in W and ops.ff_block_supported(inner):
+            # K8 (level 0): LayerNorm -> GEGLU -> output projection + residual in one kernel; the [rows][4*inner]
+            # intermediate (the largest tensor of the forward) never exists, so the memory-lean row blocks have nothing to do
+            return ops.ff_block(t, W[b + ".ff.k8"], M=M)
         blk = M
         if self.ff_block_bytes:
             # memory-lean mode (set by shard_(): the per-device footprint is what the sharded modes are for): the

@@ -123,7 +123,10 @@ def test_unet_weight_ingest_covers_every_diffusers_key():
     #   transformers, 2 attentions each) as the blobs of csrc/tattn2.hip — 100 units of 8 KB + two fp32 vectors — and
     #   width 512 (transformer_in) as the stage images of csrc/tattn_fused.hip (to_out padded to the q|k|v stage size)
     k7 = 10 * (100 * 4096 + 2 * 2 * 320) + 2 * (3 * 512 * 512 + 2 * 16 * 12288)
-    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7
+    # + the K8 blobs (csrc/ff_fused.hip): the ten level-0 feed-forwards (5 spatial + 5 temporal transformers) as 300 units
+    #   of 8 KB + the fp32 biases (2 x 1280 + 320)
+    k8 = 10 * (300 * 4096 + 2 * (2 * 1280 + 320))
+    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7 + k8
     assert m.config.in_channels == 4
     sd["bogus.weight"] = torch.empty(1, device="meta")
     with pytest.raises(_lib.VdxError):
