@@ -109,8 +109,9 @@ struct K8 {
     static constexpr int ub(int s) { return UPC * (s / CSTEPS) + ubl(s % CSTEPS); }
     static constexpr int hm(int s) { return s < 0 ? NU : ub(s + 1) + NU; }
     static constexpr int nt_of(int g) { return g < NCGF ? 8 : 4; }
-    // vector-memory instructions other than weight pieces, issued at the top of step s: the next chunk's bias (24 loads)
-    static constexpr int n_b1(int s) { return s % CSTEPS == KM ? 24 : 0; }
+    // vector-memory instructions other than weight pieces, issued at the top of step s: the next chunk's bias (8 loads;
+    // tools/k8_check_waits.py compares these counts and every wait with the emitted ISA)
+    static constexpr int n_b1(int s) { return s % CSTEPS == KM ? 8 : 0; }
     static constexpr int inflight(int s) { return 2 * (hm(s - 1) - ub(s + 2)) + n_b1(s); }
 
     struct Frag {
@@ -306,11 +307,16 @@ struct K8 {
     __device__ __forceinline__ void load_b1(State& st, const gf32* b) {
         const int o = opaque(4 * q4);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            st.av[0][j] = *(const gf32x4*)(b + o + 16 * j);
+            st.ag[0][j] = *(const gf32x4*)(b + 64 + o + 16 * j);
+        }
+#pragma unroll
+        for (int i = 1; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                st.av[i][j] = *(const gf32x4*)(b + o + 16 * j);
-                st.ag[i][j] = *(const gf32x4*)(b + 64 + o + 16 * j);
+                st.av[i][j] = st.av[0][j];
+                st.ag[i][j] = st.ag[0][j];
             }
     }
 

@@ -252,3 +252,22 @@ def test_k7b_packing_matches_kernel_indexing(Fr, rot):
     assert blob.dtype == torch.float16 and blob.numel() == 100 * 4096 + 2 * 2 * inner
     out = Wave(blob.numpy(), inner, Fr, rot).run(p0(t.numpy(), 1e-5), t.numpy())
     assert np.abs(out - ref).max() <= 3e-3 * np.abs(ref).max() + 3e-3
+
+
+def test_k8_counted_waits_match_the_emitted_isa(tmp_path):
+    """csrc/ff_fused.hip waits with `s_waitcnt vmcnt(N)`, N derived from a model of every vector-memory instruction a wave
+    issues per chunk.  The model is only right while the compiler emits exactly the loads the source counts, where it
+    counts them (hipcc once merged 24 identical bias loads into 8: the wait then let a weight unit be read before it
+    had landed).  tools/k8_check_waits.py re-derives the schedule and compares it with the ISA of this very source."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    pkg = os.path.join(ROOT, "decentralised-verification-and-distributed-execution-of-large-scale-video-diffusion-models_amd")
+    out = tmp_path / "ff_fused.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "--cuda-device-only", "-S",
+                    "-I", os.path.join(ROOT, "include"), "-I", os.path.join(pkg, "csrc"), os.path.join(pkg, "csrc", "ff_fused.hip"), "-o", str(out)],
+                   check=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k8_check_waits.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -968,3 +968,20 @@ def test_ff_block_large_mean_and_outliers(gpu):
     out = ops.ff_block(t.half().to(gpu), blob, M=M)
     assert bool(torch.isfinite(out.float()).all())
     close(out, ref, tol=6e-3)
+
+
+def test_ff_block_run_to_run_bits_at_full_size(gpu):
+    """Nine rounds of tiles per workgroup, every wave's counted waits under load: the bits must repeat (a wait that counts
+    more vector-memory instructions than the ISA holds lets a weight unit be read before it has landed — seen once as a
+    run-to-run difference of the whole forward, never at small sizes)."""
+    ops, _ = _ops()
+    from vdx import packing
+    g = torch.Generator(device=gpu).manual_seed(3)
+    inner, M = 320, 2 * 24 * 72 * 128
+    r = lambda *sh, k=1.0: (torch.randn(*sh, device=gpu, generator=g) * k).half()      # noqa: E731
+    blob = packing.pack_k8(r(8 * inner, inner, k=0.06), r(8 * inner, k=0.1), r(inner, 4 * inner, k=0.03), r(inner, k=0.1),
+                           r(inner, k=0.2) + 1, r(inner, k=0.1))
+    t = r(M, inner)
+    first = ops.ff_block(t, blob, M=M).clone()
+    for _ in range(6):
+        assert torch.equal(ops.ff_block(t, blob, M=M), first)
