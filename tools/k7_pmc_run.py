@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Dev tool: a few launches of the fused temporal-attention kernel at level-0 size, for rocprofv3 --pmc passes."""
+"""Dev tool: a few launches of the fused temporal-attention kernels (K7) and of the fused feed-forward kernel (K8) at
+level-0 size, for rocprofv3 --pmc passes."""
 import os
 import sys
 
@@ -29,3 +30,16 @@ for inner in (320, 512):
             for _ in range(4):
                 ops.temporal_attn_block2(t[:M2], blob, B=B, F=F2, HW=HW, out=out[:M2])
         torch.cuda.synchronize()
+
+# K8 (csrc/ff_fused.hip), F = 24 and 16
+inner = 320
+r = lambda *sh, k=1.0: (torch.randn(*sh, device=dev) * k).half()   # noqa: E731
+blob = packing.pack_k8(r(8 * inner, inner, k=0.06), r(8 * inner, k=0.1), r(inner, 4 * inner, k=0.03), r(inner, k=0.1), r(inner, k=0.2) + 1, r(inner, k=0.1))
+for F2 in (24, 16):
+    M2 = 2 * F2 * 72 * 128
+    t = r(M2, inner)
+    out = torch.empty_like(t)
+    for _ in range(4):
+        ops.ff_block(t, blob, M=M2, out=out)
+    torch.cuda.synchronize()
+    del t, out
