@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("frames", C.c_int32), ("hw", C.c_int32),
         ("rows_per_bias2", C.c_int32), ("ldb2", C.c_int32), ("epilogue", C.c_int32),
         ("row_begin", C.c_int32), ("row_end", C.c_int32),
-        ("ksplit", C.c_int32), ("reserved0", C.c_int32), ("workspace", C.c_void_p),
+        ("ksplit", C.c_int32), ("wset_rows", C.c_int32), ("workspace", C.c_void_p), ("wset_bias", C.c_void_p),
     ]
 
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "vdx_groupnorm_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "vdx_groupnorm_workspace_part": (_sz, [_i, _i, _i, _i, _i]),
     "vdx_groupnorm_part_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "vdx_groupnorm_fold_linear_f16": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vdx_layernorm_f16": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "vdx_flash_attn_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "vdx_flash_attn_rows_f16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),

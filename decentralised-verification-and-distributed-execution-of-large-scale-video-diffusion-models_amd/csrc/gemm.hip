@@ -463,6 +463,7 @@ static int gemm_prepare(const vdx_gemm_args* a, GemmP& p, bool& geglu, int& forc
     p.ldb2 = a->ldb2 > 0 ? a->ldb2 : a->N;
     VDX_CHECK(p.ldb2 % 8 == 0, "gemm: ldb2 must be a multiple of 8");
     p.ntn = 0; p.ntm = 0; p.ksplit = 0; p.partial = nullptr;
+    p.wset_rows = a->wset_rows; p.wset_bias = a->wset_bias;
     geglu = (a->epilogue & VDX_EPI_GEGLU) != 0;
     force = (a->epilogue >> 8) & 15;   // kernel variant override (0 = automatic)
     if (geglu) {
@@ -478,6 +479,14 @@ static int gemm_prepare(const vdx_gemm_args* a, GemmP& p, bool& geglu, int& forc
         VDX_CHECK(ws_family || force != 7, "gemm: variant 7 (weights-stationary) needs plain single-source rows, K in {320, 512, 640}, N %% 32 == 0, M %% 64 == 0");
     } else {
         VDX_CHECK(force != 7, "gemm: variant 7 (weights-stationary) computes whole products (row_begin / row_end unset)");
+    }
+    if (a->wset_rows != 0) {        // a weight set per row range (GroupNorm folded into the Linear): weights-stationary kernels only
+        VDX_CHECK(a->wset_rows > 0 && a->wset_bias && a->M % a->wset_rows == 0, "gemm: wset_rows=%d needs wset_bias and M %% wset_rows == 0", a->wset_rows);
+        VDX_CHECK(!a->bias && !a->bias2 && !a->residual && !geglu && a->mode == VDX_GEMM_PLAIN && a->ksplit <= 1,
+                  "gemm: weight sets take no bias / bias2 / residual / GEGLU / split-K (fold them into wset_bias)");
+        if (!ws_family && whole) ws_family = vdx_gemm_ws_family(p, a->mode, geglu);      // (also below the automatic row threshold)
+        VDX_CHECK(ws_family == 1 || ws_family == 2 || ws_family == 4, "gemm: weight sets run on the weights-stationary kernels (K = 320 / 640, whole products)");
+        VDX_CHECK(a->wset_rows % 64 == 0, "gemm: wset_rows must be a multiple of 64");
     }
     switch (a->mode) {
         case VDX_GEMM_PLAIN:

@@ -16,6 +16,8 @@ struct GemmP {
     int m_begin;      // first row computed (tiles start here)
     int ksplit;       // > 1: every tile is computed by `ksplit` blocks, each over a slice of the K tiles, which leave their
     float* partial;   //      fp32 accumulators in a slab of `partial`; vdx_gemm_reduce_kernel sums the slabs and runs the epilogue
+    int wset_rows;    // > 0: one weight set (w + s*N*K, wset_bias + s*N) per `wset_rows` rows (weights-stationary kernels only)
+    const float* wset_bias;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

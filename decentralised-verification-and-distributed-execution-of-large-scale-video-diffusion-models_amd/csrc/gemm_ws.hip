@@ -47,7 +47,10 @@ struct WsP {
     int nch;        // chunks in all (M / ROWS)
 };
 
-template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE>
+// WSET: one weight set per p.wset_rows rows (a GroupNorm folded into this Linear, norm.hip gn_fold_kernel): the register
+// slice is reloaded when the walk enters the next set (a multiple of the chunk height), and the set's fp32 bias is the
+// initial accumulator of its chunks.
+template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE, bool WSET = false>
 struct Ws {
     static constexpr int KS = K / 32;               // MFMA K steps
     static constexpr int MT = ROWS / 16;            // 16-row groups per chunk
@@ -68,6 +71,8 @@ struct Ws {
     const f16* a_src;            // this lane's DMA source for row (lane>>3) of 8-row block 0, sub-tile 0
     f16x8 wf[KS][2];
     f16x8 bv;
+    int set_left;                // WSET: chunks of the current weight set still to walk (block-uniform)
+    int cur_set;
 #ifdef VDX_STAMPS
     unsigned long long t_bar = 0, t_iss = 0, t_wait = 0, t_last = 0;
 #endif
@@ -128,11 +133,36 @@ struct Ws {
     }
     // K step 0 starts from the constant 0 (an inline operand of the MFMA): no accumulator clearing
     __device__ __forceinline__ void mfma_step(int s, const f16x8 (&af)[MT], Acc& acc) {
-        const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 z0 = (f32x4){0.f, 0.f, 0.f, 0.f}, z1 = z0;
+        if (WSET && s == 0) {       // the set's bias = the initial accumulators; it lives in LDS (8 more registers held across the
+            int o = bias_off();     // chunk loop spill the K = 640 kernel), re-read per chunk through an address the optimiser cannot hoist
+            asm volatile("" : "+v"(o));
+            z0 = *(const f32x4*)(smem + o);
+            z1 = *(const f32x4*)(smem + o + 16);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], af[i], s == 0 ? z : acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], af[i], s == 0 ? z : acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], af[i], s == 0 ? z0 : acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], af[i], s == 0 ? z1 : acc[i][1], 0, 0, 0);
+        }
+    }
+    // this wave's weight slice, MFMA A-operand layout.  MFMA row i of 16-column tile j carries weight
+    // row n0 + 8*(i>>2) + 4*j + (i&3): the lane then owns 8 CONSECUTIVE output columns
+    // (n0 + 8*fq .. +7) of row frow -> 16-byte stores.
+    __device__ __forceinline__ int bias_off() const { return NS * STAGE + (int)threadIdx.x * 32; }      // WSET: this lane's 32 bytes of LDS, behind the ring
+    __device__ __forceinline__ void load_weights(int set) {
+        const int nw = active ? n0 : 0;
+        const f16* wbase = p.w + (WSET ? (size_t)set * p.N * K : 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f16* wrow = wbase + (size_t)(nw + 8 * (frow >> 2) + 4 * j + (frow & 3)) * K + 8 * fq;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wf[s][j] = *(const f16x8*)(wrow + 32 * s);
+        }
+        if (WSET) {                  // this lane's 8 bias values -> its own 32 bytes of LDS (read back by the same lane only)
+            const float* b = p.wset_bias + (size_t)set * p.N + nw + 8 * fq;
+            *(f32x4*)(smem + bias_off()) = *(const f32x4*)b;
+            *(f32x4*)(smem + bias_off() + 16) = *(const f32x4*)(b + 4);
         }
     }
     __device__ __forceinline__ void load_res(int k, f16x8 (&rv)[MT]) {
@@ -169,6 +199,14 @@ struct Ws {
         if (RES && HAS_PREV) load_res(k - 1, rv);
         if (!active) zero(cur);
         if (!active) return;
+        if (WSET) {                                  // (block-uniform: every wave of the block walks the same chunks)
+            if (set_left == 0) {
+                cur_set += 1;
+                set_left = p.wset_rows / ROWS;
+                load_weights(cur_set);
+            }
+            set_left -= 1;
+        }
         // (reading the fragments of K step s+1 before the MFMAs of step s was measured: no gain — the other
         // wave(s) of the SIMD already cover the LDS latency)
 #pragma unroll
@@ -216,16 +254,14 @@ struct Ws {
         t_last = WS_T();
 #endif
 
-        // this wave's weight slice, MFMA A-operand layout.  MFMA row i of 16-column tile j carries weight
-        // row n0 + 8*(i>>2) + 4*j + (i&3): the lane then owns 8 CONSECUTIVE output columns
-        // (n0 + 8*fq .. +7) of row frow -> 16-byte stores.
-        const int nw = active ? n0 : 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f16* wrow = p.w + (size_t)(nw + 8 * (frow >> 2) + 4 * j + (frow & 3)) * K + 8 * fq;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) wf[s][j] = *(const f16x8*)(wrow + 32 * s);
+        cur_set = 0;
+        set_left = 0;
+        if (WSET) {
+            const int cps = p.wset_rows / ROWS;      // chunks per weight set
+            cur_set = c0 / cps;
+            set_left = cps - (c0 - cur_set * cps);
         }
+        load_weights(cur_set);
 #pragma unroll
         for (int j = 0; j < 8; ++j) bv[j] = (f16)0.f;
         if (p.bias && active) bv = *(const f16x8*)(p.bias + n0 + 8 * fq);
@@ -265,18 +301,19 @@ struct Ws {
     }
 };
 
-template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE>
+template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE, bool WSET>
 __global__ __launch_bounds__(NW * 64) void gemm_ws_kernel(const WsP q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Ws<K, NW, ROWS, GEGLU, RES, PIPE> ws(q.g, smem);
+    Ws<K, NW, ROWS, GEGLU, RES, PIPE, WSET> ws(q.g, smem);
     ws.run(q);
 }
 
-template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE>
+template <int K, int NW, int ROWS, bool GEGLU, bool RES, bool PIPE, bool WSET = false>
 int launch_ws(const GemmP& p, hipStream_t st) {
-    typedef Ws<K, NW, ROWS, GEGLU, RES, PIPE> W;
-    constexpr int lds = W::NS * W::STAGE + (GEGLU ? GELU_TAB_BYTES : 0);
-    auto kern = gemm_ws_kernel<K, NW, ROWS, GEGLU, RES, PIPE>;
+    typedef Ws<K, NW, ROWS, GEGLU, RES, PIPE, WSET> W;
+    static_assert(!(WSET && GEGLU), "weight sets run the plain epilogue");
+    constexpr int lds = W::NS * W::STAGE + (GEGLU ? GELU_TAB_BYTES : 0) + (WSET ? NW * 64 * 32 : 0);
+    auto kern = gemm_ws_kernel<K, NW, ROWS, GEGLU, RES, PIPE, WSET>;
     // one-time LDS opt-in; a function-local static is initialised exactly once even under concurrent callers
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr_rc != hipSuccess) return vdx_fail("gemm_ws: cannot reserve %d bytes of LDS", lds);
@@ -311,6 +348,14 @@ int vdx_gemm_ws_family(const GemmP& p, int mode, bool geglu) {
 }
 
 int vdx_gemm_ws_launch(const GemmP& p, int family, bool geglu, hipStream_t st) {
+    if (p.wset_rows > 0) {      // (gemm_prepare: plain epilogue, families 1 / 2 / 4)
+        switch (family) {
+            case 1: return launch_ws<320, 10, 64, false, false, false, true>(p, st);
+            case 2: return launch_ws<320, 8, 64, false, false, true, true>(p, st);
+            case 4: return launch_ws<640, 8, 32, false, false, true, true>(p, st);
+        }
+        return vdx_fail("gemm_ws: weight sets on family %d", family);
+    }
     switch (family) {
         case 1: return launch_ws_epi<320, 10, 64, false>(p, geglu, st);
         case 2: return launch_ws_epi<320, 8, 64, true>(p, geglu, st);

@@ -245,11 +245,12 @@ extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2,
     return vdx_groupnorm_part_f16(x, c1, ldx, x2, c2, ldx2, gamma, beta, eps, G, n_samples, rows_per_sample, silu, y, ldy,
                                   workspace, 0, stream);
 }
-extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
-                                      const void* gamma, const void* beta, float eps, int G,
-                                      int n_samples, int rows_per_sample, int silu, void* y, int ldy,
-                                      void* workspace, int partition_samples, vdx_stream_t stream) {
-    VDX_CHECK(x && gamma && beta && y && workspace, "groupnorm: null pointer");
+// statistics (+ per-channel scale / shift) always; the apply pass unless `stats_only` (the fold into a following Linear)
+static int gn_run(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
+                  const void* gamma, const void* beta, float eps, int G,
+                  int n_samples, int rows_per_sample, int silu, void* y, int ldy,
+                  void* workspace, int partition_samples, bool stats_only, GnP& p, vdx_stream_t stream) {
+    VDX_CHECK(x && gamma && beta && (y || stats_only) && workspace, "groupnorm: null pointer");
     const int C = c1 + c2;
     VDX_CHECK(c1 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "groupnorm: c1=%d c2=%d must be multiples of 8", c1, c2);
     VDX_CHECK((c2 == 0) == (x2 == nullptr), "groupnorm: x2/c2 mismatch");
@@ -257,7 +258,6 @@ extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void
     VDX_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && (c2 == 0 || ldx2 % 8 == 0), "groupnorm: leading dims must be multiples of 8");
     VDX_CHECK(n_samples > 0 && rows_per_sample > 0, "groupnorm: empty input");
     VDX_CHECK(C / 8 <= 1024, "groupnorm: C=%d too wide", C);
-    GnP p;
     p.x = (const f16*)x; p.x2 = (const f16*)x2; p.c1 = c1; p.c2 = c2; p.ldx = ldx; p.ldx2 = ldx2;
     p.C = C; p.G = G; p.cpg = C / G; p.nvec = C / 8;
     p.n_samples = n_samples; p.rps = rows_per_sample;
@@ -272,12 +272,66 @@ extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void
     hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), (2 * (size_t)p.krows * C + p.krows + 2 * (size_t)G * p.krows) * sizeof(float), st, p);
     const int nsg = n_samples * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, st, p, (const f16*)gamma, (const f16*)beta, eps);
+    if (stats_only) return vdx_launch_status("vdx_groupnorm_f16 (statistics)");
     dim3 agrid((rows_per_sample + p.apply_rows - 1) / p.apply_rows, n_samples);
     if (silu)
         hipLaunchKernelGGL(gn_apply_kernel<true>, agrid, dim3(nt), 0, st, p, (f16*)y, ldy);
     else
         hipLaunchKernelGGL(gn_apply_kernel<false>, agrid, dim3(nt), 0, st, p, (f16*)y, ldy);
     return vdx_launch_status("vdx_groupnorm_f16");
+}
+extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
+                                      const void* gamma, const void* beta, float eps, int G,
+                                      int n_samples, int rows_per_sample, int silu, void* y, int ldy,
+                                      void* workspace, int partition_samples, vdx_stream_t stream) {
+    GnP p;
+    return gn_run(x, c1, ldx, x2, c2, ldx2, gamma, beta, eps, G, n_samples, rows_per_sample, silu, y, ldy, workspace,
+                  partition_samples, false, p, stream);
+}
+
+// ---- GroupNorm folded into the Linear that follows it (Transformer2DModel / TransformerTemporalModel: norm -> proj_in,
+// no activation between them).  With the per-(sample, channel) scale a and shift b of the statistics,
+//     W . (a x + b) + bias  =  (W diag(a_s)) . x  +  (bias + W . b_s):
+// one weight matrix and one bias vector PER SAMPLE (48 x 200 KB at level 0) and the GEMM reads the raw rows — the
+// normalised tensor (one read + one write of the activation) never exists.  The mean term of b_s is formed with the
+// ROUNDED fp16 weights the GEMM will use, W16 = fp16(W a):  bias_s = bias + W.beta - W16 . mean_s,  so that the GEMM
+// result is exactly sum W16 (x - mean) + const: the rounding of W16 multiplies deviations, not a large mean.
+// One wave per (sample, output row).
+__global__ void gn_fold_kernel(const float* ab, const f16* beta, const f16* w, const f16* bias, int C, int N, int n_samples,
+                               f16* w_out, float* bias_out) {
+    const int lane = threadIdx.x & 63;
+    const long long sn = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (sn >= (long long)n_samples * N) return;
+    const int sample = (int)(sn / N), n = (int)(sn % N);
+    const float* abs_ = ab + (size_t)sample * C * 2;
+    const f16* wr = w + (size_t)n * C;
+    f16* wo = w_out + ((size_t)sample * N + n) * C;
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float a = abs_[2 * c], b = abs_[2 * c + 1], wv = (float)wr[c], be = (float)beta[c];
+        const f16 w16 = (f16)(wv * a);
+        wo[c] = w16;
+        const float mean = a != 0.f ? (be - b) / a : 0.f;       // (a = rstd * gamma; gamma = 0: the channel contributes beta only)
+        acc += wv * be - (float)w16 * mean;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) bias_out[(size_t)sample * N + n] = acc + (bias ? (float)bias[n] : 0.f);
+}
+
+extern "C" int vdx_groupnorm_fold_linear_f16(const void* x, int C, int ldx, const void* gamma, const void* beta, float eps, int G,
+                                             int n_samples, int rows_per_sample, void* workspace, int partition_samples,
+                                             const void* w, const void* bias, int N, void* w_out, void* bias_out,
+                                             vdx_stream_t stream) {
+    VDX_CHECK(w && w_out && bias_out, "groupnorm_fold_linear: null pointer");
+    VDX_CHECK(N > 0 && (long long)n_samples * N < (1ll << 31), "groupnorm_fold_linear: bad N");
+    GnP p;
+    if (const int rc = gn_run(x, C, ldx, nullptr, 0, 0, gamma, beta, eps, G, n_samples, rows_per_sample, 0, nullptr, 0, workspace,
+                              partition_samples, true, p, stream))
+        return rc;
+    const long long waves = (long long)n_samples * N;
+    hipLaunchKernelGGL(gn_fold_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p.ab, (const f16*)beta,
+                       (const f16*)w, (const f16*)bias, C, N, n_samples, (f16*)w_out, (float*)bias_out);
+    return vdx_launch_status("vdx_groupnorm_fold_linear_f16");
 }
 
 // ---- LayerNorm: one wave per row, row cached in registers ---------------------------------

@@ -58,15 +58,56 @@ def _ksplit_workspace(device, nbytes):
     return ws
 
 
+def groupnorm_linear_supported(C: int, N: int, rows_per_sample: int) -> bool:
+    """Shapes `groupnorm_linear` folds (the weights-stationary GEMM families with a weight set per sample)."""
+    return C in (320, 640) and N % 32 == 0 and rows_per_sample % 64 == 0
+
+
+def groupnorm_linear(x, gamma, beta, w, bias, *, groups, n_samples, rows_per_sample, eps, partition_samples=0, out=None):
+    """Linear(GroupNorm(x)) without the normalised tensor (`norm` -> `proj_in` of the transformer blocks): the statistics
+    pass, then one weight matrix + fp32 bias per sample (`vdx_groupnorm_fold_linear_f16`), then the weights-stationary GEMM
+    on the raw rows with `wset_rows = rows_per_sample`."""
+    lib = _lib.load()
+    r, Cc, ldx = _rows(x, "x")
+    M = n_samples * rows_per_sample
+    N, K = w.shape
+    if r < M or K != Cc or gamma.numel() != Cc or beta.numel() != Cc:
+        raise VdxError(f"groupnorm_linear: x [{r}][{Cc}], w [{N}][{K}], gamma {gamma.numel()}: shapes do not match")
+    if not groupnorm_linear_supported(Cc, N, rows_per_sample) or not w.is_contiguous():
+        raise VdxError(f"groupnorm_linear: C={Cc}, N={N}, rows_per_sample={rows_per_sample} not supported")
+    need = lib.vdx_groupnorm_workspace_part(n_samples, rows_per_sample, Cc, groups, partition_samples)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    w_s = torch.empty((n_samples * N, K), dtype=torch.float16, device=x.device)
+    b_s = torch.empty((n_samples, N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.vdx_groupnorm_fold_linear_f16(_p(x, "x"), Cc, ldx, _p(gamma, "gamma"), _p(beta, "beta"), float(eps), groups,
+                                                 n_samples, rows_per_sample, ws.data_ptr(), partition_samples, _p(w, "w"),
+                                                 _p(bias, "bias"), N, w_s.data_ptr(), b_s.data_ptr(), _stream()),
+               "vdx_groupnorm_fold_linear_f16")
+    return gemm(x, w_s, M=M, wset_rows=rows_per_sample, wset_bias=b_s, out=out)
+
+
 def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=0, residual=None,
-         out=None, geglu=False, conv=None, tconv=None, variant=0, row_begin=0, row_end=0, allow_ksplit=False, ksplit=0):
+         out=None, geglu=False, conv=None, tconv=None, variant=0, row_begin=0, row_end=0, allow_ksplit=False, ksplit=0,
+         wset_rows=0, wset_bias=None):
     """out[M][N] = epi(gather(a|a2)[M][K] @ w[N][K]^T).  See include/vdx.h `vdx_gemm_args`.
     `allow_ksplit`: the tail of the product (less than half a round of big tiles) may run as K slices + a fixed-order
     reduction (vdx_gemm_plan_ksplit) — faster on the 16-frame windows, not bit-identical to the unsplit order (the
-    callers that rely on row-split bit-identity do not pass it).  `ksplit`: pin it for rows [row_begin, row_end)."""
+    callers that rely on row-split bit-identity do not pass it).  `ksplit`: pin it for rows [row_begin, row_end).
+    `wset_rows` / `wset_bias`: one weight set per `wset_rows` rows, w = [M / wset_rows][N][K] and an fp32 bias per set
+    (a GroupNorm folded into the Linear: `groupnorm_linear`)."""
     lib = _lib.load()
     ar, c1, lda = _rows(a, "a")
     N, K = w.shape
+    if wset_rows:
+        if M % wset_rows or N % (M // wset_rows) or wset_bias is None or wset_bias.dtype != torch.float32:
+            raise VdxError("gemm: wset_rows needs M % wset_rows == 0, w = [sets * N][K] and an fp32 wset_bias [sets][N]")
+        N //= M // wset_rows
+        if wset_bias.numel() != (M // wset_rows) * N or not wset_bias.is_contiguous():
+            raise VdxError("gemm: wset_bias must be contiguous [sets][N]")
     if not w.is_contiguous():
         raise VdxError("w: must be contiguous [N][K]")
     c2 = 0
@@ -117,10 +158,12 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     g.M, g.N, g.K, g.mode, g.c1, g.c2 = M, N, K, mode, c1, c2
     g.lda, g.ldo = lda, ldo
     g.epilogue = (EPI_GEGLU if geglu else 0) | ((variant & 15) << 8)   # variant: kernel override (tests/tuning)
+    if wset_rows:
+        g.wset_rows, g.wset_bias = wset_rows, wset_bias.data_ptr()
     # One product, up to two launches: whole rounds of 256 big tiles, then the rest on whatever tile suits it
     # (vdx_gemm_plan; the bits do not depend on the split).  A pinned variant or an explicit row range is left alone.
     spans = [(row_begin, row_end, ksplit)]
-    if variant == 0 and row_begin == 0 and row_end == 0 and ksplit == 0:
+    if variant == 0 and row_begin == 0 and row_end == 0 and ksplit == 0 and not wset_rows:
         key = (M, N, K, mode, geglu, a2 is not None, bias2 is not None, allow_ksplit)      # everything the plan depends on
         plan_ = _PLAN_CACHE.get(key)
         if plan_ is None:
@@ -149,8 +192,8 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
         _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
         ev1.record()
         rows = (re_ or M) - rb
-        name = gemm_kernel_name(rows, N, K, mode, geglu, variant, single_source=a2 is None and bias2 is None,
-                                residual=residual is not None, whole=(rb == 0 and re_ in (0, M)))
+        name = gemm_kernel_name(rows, N, K, mode, geglu, 7 if wset_rows else variant, single_source=a2 is None and bias2 is None,
+                                residual=residual is not None, whole=(rb == 0 and re_ in (0, M)), wset=bool(wset_rows))
         if ks > 1:
             name = f"gemm_kernel<256, 320, 4, 2, {mode}, false, {'true' if mode else 'false'}, 1> split-K + reduce"
         PROFILE.append((name, 2.0 * rows * N * K, ev0, ev1, (rows, N, K)))
@@ -165,7 +208,7 @@ WS_MIN_ROWS = 16384   # gemm.hip: smallest M the weights-stationary K=320 kernel
 
 
 def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: int = 0, single_source: bool = True,
-                     residual: bool = False, whole: bool = True) -> str:
+                     residual: bool = False, whole: bool = True, wset: bool = False) -> str:
     """Name of the instantiation vdx_gemm_f16 launches (as rocprofv3 prints it) for M rows (`whole`: the call covers
     the whole product — the weights-stationary kernels take no row ranges)."""
     v = variant
@@ -177,7 +220,7 @@ def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: in
             fam = (K, 8, 32, True)
         if fam:
             b = lambda x: "true" if x else "false"
-            return f"gemm_ws_kernel<{fam[0]}, {fam[1]}, {fam[2]}, {b(geglu)}, {b(residual and not geglu)}, {b(fam[3])}>"
+            return f"gemm_ws_kernel<{fam[0]}, {fam[1]}, {fam[2]}, {b(geglu)}, {b(residual and not geglu)}, {b(fam[3])}, {b(wset)}>"
     if v == 0:
         nt320 = (N + 319) // 320
         fits = nt320 * 320 * 4 <= N * 5 and M >= 1024

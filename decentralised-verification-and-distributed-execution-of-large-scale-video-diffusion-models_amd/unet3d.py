@@ -76,6 +76,7 @@ class UNet3DConditionModel(nn.Module):
         self.ff_block_bytes = None     # memory-lean feed-forward (see _ff); shard_() turns it on
         self.lean_concat = True        # (with ff_block_bytes set) concat GroupNorm -> conv1 over pieces of whole frames
         self.lean_attn = True          # (with ff_block_bytes set) spatial self-attention over image halves
+        self.fold_norm_proj_in = True  # GroupNorm -> proj_in as per-sample weights where the Linear is weights-stationary
         self.fuse_ff = True            # K8 where the width allows (False: LayerNorm, GEGLU GEMM, GEMM + residual)
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
@@ -409,6 +410,20 @@ class UNet3DConditionModel(nn.Module):
             del gg
         return out
 
+    def _norm_proj_in(self, p, x, n_samples, rows_per_sample, M):
+        """`norm` -> `proj_in` at the entry of a transformer: GroupNorm (eps 1e-6, no activation) then a Linear.  Where the
+        Linear runs on the weights-stationary kernels (levels 0 / 1, transformer_in) the norm is FOLDED into it — per-sample
+        weights and an fp32 bias from the statistics, the GEMM reads the raw rows (ops.groupnorm_linear): the normalised
+        tensor, one read and one write of the activation, never exists."""
+        W, g = self.W, self.cfg.norm_num_groups
+        w = W[p + ".proj_in.weight"]
+        if self.fold_norm_proj_in and M >= 16384 and M % 64 == 0 and ops.groupnorm_linear_supported(x.shape[1], w.shape[0], rows_per_sample):
+            return ops.groupnorm_linear(x, W[p + ".norm.weight"], W[p + ".norm.bias"], w, W[p + ".proj_in.bias"], groups=g,
+                                        n_samples=n_samples, rows_per_sample=rows_per_sample, eps=1e-6)
+        n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=n_samples,
+                          rows_per_sample=rows_per_sample, eps=1e-6, silu_act=False)
+        return ops.gemm(n, w, M=M, bias=W[p + ".proj_in.bias"])
+
     def _spatial_transformer(self, p, x, ehs_pad, n_img, F, hh, ww):
         W, g = self.W, self.cfg.norm_num_groups
         S, M = hh * ww, n_img * hh * ww
@@ -416,10 +431,7 @@ class UNet3DConditionModel(nn.Module):
         heads = C // 64
         scale = 64 ** -0.5
         b = p + ".transformer_blocks.0"
-        n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=n_img,
-                          rows_per_sample=S, eps=1e-6, silu_act=False)
-        t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
-        del n
+        t = self._norm_proj_in(p, x, n_img, S, M)
         # --- self-attention: q | k | v from ONE projection; the flash kernel takes V as rows (transposed by its LDS read),
         # so there is no V^T product and no padded copy for token counts that are no multiple of 8 (latent 40x72 ->
         # 5x9 = 45 tokens at the mid block, InferNet/tests/test_pipeline.py:293; 16x16 -> 2x2 = 4, InferNet/neurons/miner.py:491-494)
@@ -478,10 +490,7 @@ class UNet3DConditionModel(nn.Module):
         M = B * F * S
         scale = 64 ** -0.5
         b = p + ".transformer_blocks.0"
-        n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=B,
-                          rows_per_sample=F * S, eps=1e-6, silu_act=False)
-        t = ops.gemm(n, W[p + ".proj_in.weight"], M=M, bias=W[p + ".proj_in.bias"])
-        del n
+        t = self._norm_proj_in(p, x, B, F * S, M)
         fused = self.fuse_temporal_attention and f"{b}.attn1.k7_qkv" in W and ops.temporal_attn_block_supported(t.shape[1], F)
         fused2 = self.fuse_temporal_attention and f"{b}.attn1.k7b" in W and ops.temporal_attn_block2_supported(t.shape[1], F)
         for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):

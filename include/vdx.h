@@ -72,8 +72,12 @@ typedef struct vdx_gemm_args {
                              (fp32 partial slabs in `workspace`) + a fixed-order reduction that runs the epilogue.  Fills
                              the chip when the call has far fewer than 256 tiles (the tail of a product).  Changes the
                              summation order of these rows (NOT bit-identical to ksplit = 0; deterministic)          */
-    int32_t reserved0;
+    int32_t wset_rows;    /* > 0: ONE WEIGHT SET PER `wset_rows` ROWS — rows [s*wset_rows, (s+1)*wset_rows) use w + s*N*K and
+                             wset_bias + s*N (a GroupNorm folded into this Linear: vdx_groupnorm_fold_linear_f16).  Plain
+                             mode on the weights-stationary kernels only (K = 320 / 640, M and wset_rows multiples of 64),
+                             no bias / bias2 / residual / GEGLU                                                    */
     void* workspace;      /* ksplit > 1: >= tiles * ksplit * 327 680 bytes (vdx_gemm_plan_ksplit), 16-byte aligned    */
+    const float* wset_bias; /* wset_rows > 0: fp32 [M / wset_rows][N], the initial accumulators                          */
 } vdx_gemm_args;
 
 int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream);
@@ -126,6 +130,14 @@ int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, in
  * sample's result then has the same bits alone, in part of a batch or in the whole batch (callers that split a batch
  * to save memory, or decode frames one by one like fsdp_chunked_coherent.py:219-225, pass the full batch size). */
 size_t vdx_groupnorm_workspace_part(int n_samples, int rows_per_sample, int C, int G, int partition_samples);
+/* GroupNorm folded into the Linear that follows it without an activation (Transformer2DModel / TransformerTemporalModel:
+ * `norm` -> `proj_in`): the statistics pass of vdx_groupnorm_part_f16, then per sample s
+ *   w_out[s] = fp16(w diag(scale_s))  [N][C],   bias_out[s] = bias + w.beta - w_out[s].mean_s  (fp32 [N])
+ * so that  vdx_gemm_f16(x, w_out, wset_rows = rows_per_sample, wset_bias = bias_out)  ==  Linear(GroupNorm(x)) without
+ * the normalised tensor ever being written.  w_out: n_samples*N*C fp16, bias_out: n_samples*N fp32.              */
+int vdx_groupnorm_fold_linear_f16(const void* x, int C, int ldx, const void* gamma, const void* beta, float eps, int G,
+                                  int n_samples, int rows_per_sample, void* workspace, int partition_samples,
+                                  const void* w, const void* bias, int N, void* w_out, void* bias_out, vdx_stream_t stream);
 int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
                            const void* gamma, const void* beta, float eps, int G,
                            int n_samples, int rows_per_sample, int silu,

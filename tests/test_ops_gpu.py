@@ -985,3 +985,41 @@ def test_ff_block_run_to_run_bits_at_full_size(gpu):
     first = ops.ff_block(t, blob, M=M).clone()
     for _ in range(6):
         assert torch.equal(ops.ff_block(t, blob, M=M), first)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,N,n_samples,rps", [(320, 320, 3, 128), (320, 512, 2, 192), (640, 640, 5, 64), (320, 320, 48, 576), (640, 640, 2, 4608)])
+def test_groupnorm_folded_into_linear(gpu, C, N, n_samples, rps):
+    """`norm` -> `proj_in` of the transformer blocks as per-sample weights + bias on the raw rows
+    (vdx_groupnorm_fold_linear_f16 + vdx_gemm_args.wset_rows) against the fp32 statement and the un-fused pair."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(C + N + n_samples)
+    M = n_samples * rps
+    x = h(torch.randn(n_samples, rps, C, generator=g) * (0.5 + torch.rand(n_samples, 1, 1, generator=g) * 2) + torch.randn(n_samples, 1, C, generator=g))
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.2 * torch.randn(C, generator=g))
+    w, b = h(torch.randn(N, C, generator=g) * 0.05), h(torch.randn(N, generator=g) * 0.1)
+    ref = F.linear(F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1), w, b).reshape(M, N)
+    xd = x.reshape(M, C).half().to(gpu)
+    out = ops.groupnorm_linear(xd, gamma.half().to(gpu), beta.half().to(gpu), w.half().to(gpu), b.half().to(gpu), groups=32,
+                               n_samples=n_samples, rows_per_sample=rps, eps=1e-6)
+    close(out, ref, tol=4e-3)
+    n = ops.groupnorm(xd, gamma.half().to(gpu), beta.half().to(gpu), groups=32, n_samples=n_samples, rows_per_sample=rps, eps=1e-6,
+                      silu_act=False)
+    un = ops.gemm(n, w.half().to(gpu), M=M, bias=b.half().to(gpu))
+    close(out, un.float().cpu(), tol=4e-3)
+
+
+def test_groupnorm_folded_into_linear_large_mean(gpu):
+    """Group means 100 standard deviations out: the fold keeps the mean term in fp32 and forms it with the rounded weights
+    the GEMM uses, so the rounding of the per-sample weights multiplies deviations only."""
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(9)
+    C, N, n_samples, rps = 320, 320, 4, 256
+    M = n_samples * rps
+    x = h(torch.randn(n_samples, rps, C, generator=g) * 0.5 + 50.0 * torch.randn(n_samples, 1, C, generator=g).sign())
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.2 * torch.randn(C, generator=g))
+    w, b = h(torch.randn(N, C, generator=g) * 0.05), h(torch.randn(N, generator=g) * 0.1)
+    ref = F.linear(F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1), w, b).reshape(M, N)
+    out = ops.groupnorm_linear(x.reshape(M, C).half().to(gpu), gamma.half().to(gpu), beta.half().to(gpu), w.half().to(gpu),
+                               b.half().to(gpu), groups=32, n_samples=n_samples, rows_per_sample=rps, eps=1e-6)
+    close(out, ref, tol=6e-3)
