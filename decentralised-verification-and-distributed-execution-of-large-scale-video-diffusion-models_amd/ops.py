@@ -183,7 +183,13 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
         g.row_begin, g.row_end, g.ksplit, g.workspace = rb, re_, ks, None
         if ks > 1:
             g.workspace = _ksplit_workspace(out.device, wsb).data_ptr()
-        if PROFILE is None:
+        if PROFILE is not None:
+            rows = (re_ or M) - rb
+            name = gemm_kernel_name(rows, N, K, mode, geglu, 7 if wset_rows else variant, single_source=a2 is None and bias2 is None,
+                                    residual=residual is not None, whole=(rb == 0 and re_ in (0, M)), wset=bool(wset_rows))
+            if ks > 1:
+                name = f"gemm_kernel<256, 320, 4, 2, {mode}, false, {'true' if mode else 'false'}, 1> split-K + reduce"
+        if PROFILE is None or not _profiled(name):
             _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
             continue
         # bench.py instrumentation: HIP events on the launch stream around this one kernel
@@ -191,17 +197,17 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
         ev0.record()
         _lib.check(lib.vdx_gemm_f16(C.byref(g), _stream()), "vdx_gemm_f16")
         ev1.record()
-        rows = (re_ or M) - rb
-        name = gemm_kernel_name(rows, N, K, mode, geglu, 7 if wset_rows else variant, single_source=a2 is None and bias2 is None,
-                                residual=residual is not None, whole=(rb == 0 and re_ in (0, M)), wset=bool(wset_rows))
-        if ks > 1:
-            name = f"gemm_kernel<256, 320, 4, 2, {mode}, false, {'true' if mode else 'false'}, 1> split-K + reduce"
         PROFILE.append((name, 2.0 * rows * N * K, ev0, ev1, (rows, N, K)))
     return out
 
 
 _PLAN_CACHE = {}
 PROFILE = None   # set to a list by bench.py to collect (kernel name, algorithmic FLOPs, start, end)
+PROFILE_ONLY = None   # with PROFILE set: only launches whose kernel name contains one of these strings get events (None: all)
+
+
+def _profiled(name: str) -> bool:
+    return PROFILE_ONLY is None or any(s_ in name for s_ in PROFILE_ONLY)
 
 
 WS_MIN_ROWS = 16384   # gemm.hip: smallest M the weights-stationary K=320 kernel is picked for
@@ -403,18 +409,21 @@ def flash_attn(q, k, vt, *, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, o
     orow, ocol, ldo = _rows(out, "out")
     if orow < n_seq * sq or ocol < inner:
         raise VdxError("flash_attn: out too small")
+    rec = False
     if PROFILE is not None:        # bench.py instrumentation (as in gemm): HIP events on the launch stream
+        two = sq >= 512 and skv >= 256                      # flash.hip: 64 queries per wave
+        name = f"flash_attn_kernel<{2 if two else 1}, {'true' if causal else 'false'}, {'true' if v_rows else 'false'}>"
+        rec = _profiled(name)
+    if rec:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
     fn = lib.vdx_flash_attn_rows_f16 if v_rows else lib.vdx_flash_attn_f16
     _lib.check(fn(_p(q, "q"), ldq, _p(k, "k"), ldk, _p(vt, "vt"), ldvt, _p(out, "out"), ldo,
                   n_seq, sq, skv, skv_pad, heads, seq_per_kv, float(scale), int(bool(causal)), _stream()),
                "vdx_flash_attn_rows_f16" if v_rows else "vdx_flash_attn_f16")
-    if PROFILE is not None:
+    if rec:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        two = sq >= 512 and skv >= 256                      # flash.hip: 64 queries per wave
-        name = f"flash_attn_kernel<{2 if two else 1}, {'true' if causal else 'false'}, {'true' if v_rows else 'false'}>"
         PROFILE.append((name, 4.0 * n_seq * heads * sq * skv * 64, ev0, ev1, (n_seq * sq, skv, heads * 64)))
     return out
 
@@ -487,12 +496,13 @@ def ff_block(t, packed, *, M, eps=1e-5, out=None):
         raise VdxError("ff_block: out too small")
     if out.data_ptr() == t.data_ptr():
         raise VdxError("ff_block: out may not alias t")
-    if PROFILE is not None:
+    rec = PROFILE is not None and _profiled(f"ff_fused_kernel<{inner}>")
+    if rec:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(lib.vdx_ff_block_f16(_p(t, "t"), ldt, _p(packed, "packed"), float(eps), _p(out, "out"), ldo, M, inner, _stream()),
                "vdx_ff_block_f16")
-    if PROFILE is not None:
+    if rec:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         PROFILE.append((f"ff_fused_kernel<{inner}>", 2.0 * M * inner * 12 * inner, ev0, ev1, (M, inner, 12 * inner)))
