@@ -40,7 +40,7 @@ def test_gemm_args_struct_matches_header_field_order():
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void\s*\*|int32_t)\s*", "", decl)
+        decl = re.sub(r"^(const\s+)?(void\s*\*|float\s*\*|int32_t)\s*", "", decl)
         names += [n.strip().lstrip("*") for n in decl.split(",")]
     assert names == [f[0] for f in _lib.GemmArgs._fields_]
 
