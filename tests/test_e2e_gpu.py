@@ -72,10 +72,10 @@ def test_prompt_ids_to_frames_and_metrics(gpu, tmp_path):
     print(f"e2e: latent rel-L2 {err:.3e}; frames |diff| mean {diff.mean():.3f} max {diff.max()} ({(diff <= 2).mean() * 100:.2f} % within 2 levels)")
     assert err <= 2e-2
     assert diff.mean() < 0.6 and (diff <= 2).mean() > 0.97
-    # reference quirk carried through the decoder: frames 0 and T-1 both decode the all-zero latent (they sit in
-    # different decode batches here, so they agree to rounding, not to the bit)
-    d0 = np.abs(frames[0].astype(np.int32) - frames[-1].astype(np.int32))
-    assert d0.max() <= 2 and d0.mean() < 0.1
+    # reference quirk carried through the decoder: frames 0 and T-1 both decode the all-zero latent.  They sit in different
+    # decode batches here; the decoder is batch-invariant (GroupNorm statistics with a fixed slab partition,
+    # per-image attention), so they agree to the bit
+    assert np.array_equal(frames[0], frames[-1])
 
     # ---- result row (:227-276, 313-333) -------------------------------------------------------------
     ti = metrics.boundary_l1(frames, info["ranges"])
