@@ -254,6 +254,22 @@ def test_k7b_packing_matches_kernel_indexing(Fr, rot):
     assert np.abs(out - ref).max() <= 3e-3 * np.abs(ref).max() + 3e-3
 
 
+def test_k7_counted_waits_match_the_emitted_isa(tmp_path):
+    """The same check for csrc/tattn2.hip (K7, second design): all 65 steps of its five frame specialisations — DMA pieces,
+    plain loads, stores and the wait of every step as tools/k7b_check_waits.py derives them, against the emitted ISA."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    pkg = os.path.join(ROOT, "decentralised-verification-and-distributed-execution-of-large-scale-video-diffusion-models_amd")
+    out = tmp_path / "tattn2.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "--cuda-device-only", "-S",
+                    "-I", os.path.join(ROOT, "include"), "-I", os.path.join(pkg, "csrc"), os.path.join(pkg, "csrc", "tattn2.hip"), "-o", str(out)],
+                   check=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k7b_check_waits.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count(" 0 mismatching") == 5, r.stdout + r.stderr
+
+
 def test_k8_counted_waits_match_the_emitted_isa(tmp_path):
     """csrc/ff_fused.hip waits with `s_waitcnt vmcnt(N)`, N derived from a model of every vector-memory instruction a wave
     issues per chunk.  The model is only right while the compiler emits exactly the loads the source counts, where it
