@@ -1023,3 +1023,20 @@ def test_groupnorm_folded_into_linear_large_mean(gpu):
     out = ops.groupnorm_linear(x.reshape(M, C).half().to(gpu), gamma.half().to(gpu), beta.half().to(gpu), w.half().to(gpu),
                                b.half().to(gpu), groups=32, n_samples=n_samples, rows_per_sample=rps, eps=1e-6)
     close(out, ref, tol=6e-3)
+
+
+def test_ff_block_strided_rows(gpu):
+    """t and out as column blocks of wider matrices (leading dimensions larger than the width): same bits as contiguous rows."""
+    ops, _ = _ops()
+    from vdx import packing
+    g = torch.Generator(device=gpu).manual_seed(8)
+    inner, M = 320, 1111
+    r = lambda *sh, k=1.0: (torch.randn(*sh, device=gpu, generator=g) * k).half()      # noqa: E731
+    blob = packing.pack_k8(r(8 * inner, inner, k=0.06), r(8 * inner, k=0.1), r(inner, 4 * inner, k=0.03), r(inner, k=0.1),
+                           r(inner, k=0.2) + 1, r(inner, k=0.1))
+    wide = r(M, 3 * inner)
+    t = wide[:, inner:2 * inner]
+    ref = ops.ff_block(t.contiguous(), blob, M=M)
+    dst = torch.zeros(M, 2 * inner + 64, dtype=torch.float16, device=gpu)
+    out = ops.ff_block(t, blob, M=M, out=dst[:, 64:64 + inner])
+    assert torch.equal(out, ref) and float(dst[:, :64].abs().max()) == 0.0 and float(dst[:, 64 + inner:].abs().max()) == 0.0
