@@ -33,6 +33,11 @@ typedef __attribute__((address_space(1))) f32x4 gf32x4;
 typedef __attribute__((address_space(1))) float gf32;
 
 __device__ __forceinline__ void wg_barrier() {
+#ifdef K8_ABL_NOBAR
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+#endif
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -215,9 +220,21 @@ struct K8 {
     }
 
     __device__ __forceinline__ f16x8 xfrag(int i, int ks) const {
+#ifdef K8_ABL_NOLDSX
+        f16x8 v;
+        for (int e = 0; e < 8; ++e) v[e] = (f16)(float)(i + ks + e + lane);
+        asm volatile("" : "+v"(v));
+        return v;
+#endif
         return *(const lf16x8*)(lds + xb[ks & 1] + (2 * i * RBB + 1024 * (ks >> 1)));
     }
     __device__ __forceinline__ f16x8 wfrag(int unit, int tile) const {
+#ifdef K8_ABL_NOLDSW      /* timing only: weight fragments from a register pattern instead of LDS */
+        f16x8 v;
+        for (int e = 0; e < 8; ++e) v[e] = (f16)(float)(unit + tile + e + lane);
+        asm volatile("" : "+v"(v));
+        return v;
+#endif
         return *(const lf16x8*)(lds + woffb + ((unit % NU) * UB + tile * 1024));
     }
 
