@@ -363,7 +363,7 @@ static int launch_ksplit(const GemmP& p, int ksplit, float* ws, hipStream_t st) 
 }
 
 // Kernel choice.  `force` (vdx_gemm_args.epilogue bits 8..11, a testing/tuning knob) pins a
-// variant: 1 = 128x128 two-stage, 2 = 256x320 two-stage (K-step 64), 3 = 256x320 four-stage ring
+// variant: 1 = 128x128 two-stage (eight waves; 9 = four waves), 2 = 256x320 two-stage (K-step 64), 3 = 256x320 four-stage ring
 // (K-step 32), 4 = 128x320 two-stage ring with two blocks per CU, 8 = 128x320 four-stage ring with eight
 // 32x160 waves, 5 = 256x64, 6 = variant 2 without the
 // split staging roles (every wave issues its share of both operands at the top of the K tile); 7 (handled in
@@ -421,13 +421,14 @@ static int pick_tile(const GemmP& p, int force, hipStream_t st) {
             return v == 1 ? launch<128, 128, 2, 2, 1, false, false, 2>(p, st) : launch<256, 320, 4, 2, 1, false, true, 2>(p, st);
     }
     switch (v) {
-        case 1: return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);
+        case 1: return launch<128, 128, 4, 2, MODE, GEGLU>(p, st);     // EIGHT waves of 32x64: two waves per SIMD (3-10 % over four 64x64 waves on the tails, same bits)
         case 2: return launch<256, 320, 4, 2, MODE, GEGLU, MODE != 0>(p, st);   // split roles pay on the gathers only
         case 6: return launch<256, 320, 4, 2, MODE, GEGLU, false>(p, st);
         case 3: return vdx_gemm_ring_launch(p, MODE, GEGLU, 0, st);
         case 4: return vdx_gemm_ring_launch(p, MODE, GEGLU, 1, st);
         case 8: return vdx_gemm_ring_launch(p, MODE, GEGLU, 2, st);
         case 5: return launch<256, 64, 4, 1, MODE, GEGLU>(p, st);
+        case 9: return launch<128, 128, 2, 2, MODE, GEGLU>(p, st);     // the four-wave form (64x64 per wave), kept for comparison
     }
     return vdx_fail("gemm: unknown kernel variant %d", v);
 }

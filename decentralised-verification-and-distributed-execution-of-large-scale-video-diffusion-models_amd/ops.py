@@ -239,9 +239,9 @@ def gemm_kernel_name(M: int, N: int, K: int, mode: int, geglu: bool, variant: in
             c2, c8, c1 = 10 * ((t256 + 255) // 256), 8 * ((t128 + 255) // 256), 3 * ((t1 + 255) // 256)
             v = 2 if (c2 <= c8 and c2 <= c1) else (8 if c8 <= c1 else 1)
     tail = f"{0 if geglu else mode}, {'true' if geglu else 'false'}"
-    split = {1: ", false, 0>", 2: ", true, 0>" if (mode != PLAIN and not geglu) else ", false, 0>", 5: ", false, 0>",
+    split = {1: ", false, 0>", 9: ", false, 0>", 2: ", true, 0>" if (mode != PLAIN and not geglu) else ", false, 0>", 5: ", false, 0>",
              6: ", false, 0>"}.get(v, ">")   # gemm_kernel's SPLIT flag and VAR (0: the product kernels)
-    return {1: "gemm_kernel<128, 128, 2, 2, ", 2: "gemm_kernel<256, 320, 4, 2, ", 3: "gemm_ring_kernel<4, 64, 4, ",
+    return {1: "gemm_kernel<128, 128, 4, 2, ", 9: "gemm_kernel<128, 128, 2, 2, ", 2: "gemm_kernel<256, 320, 4, 2, ", 3: "gemm_ring_kernel<4, 64, 4, ",
             4: "gemm_ring_kernel<2, 64, 2, ", 8: "gemm_ring_kernel<4, 32, 4, ", 5: "gemm_kernel<256, 64, 4, 1, ", 6: "gemm_kernel<256, 320, 4, 2, "}[v] + tail + split
 
 
