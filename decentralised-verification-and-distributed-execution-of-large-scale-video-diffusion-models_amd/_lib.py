@@ -25,6 +25,7 @@ class GemmArgs(C.Structure):
         ("rows_per_bias2", C.c_int32), ("ldb2", C.c_int32), ("epilogue", C.c_int32),
         ("row_begin", C.c_int32), ("row_end", C.c_int32),
         ("ksplit", C.c_int32), ("wset_rows", C.c_int32), ("workspace", C.c_void_p), ("wset_bias", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
     ]
 
 

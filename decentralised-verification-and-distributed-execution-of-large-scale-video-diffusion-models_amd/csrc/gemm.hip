@@ -531,6 +531,11 @@ extern "C" int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream) {
         VDX_CHECK(nt320 * 320 * 4 <= p.N * 5, "gemm: split-K needs N = %d to fill 320-wide tiles", p.N);
         VDX_CHECK(a->workspace && (uintptr_t)a->workspace % 16 == 0, "gemm: split-K needs a 16-byte aligned workspace");
         VDX_CHECK(tiles * a->ksplit <= (1 << 20), "gemm: split-K grid too large");
+        VDX_CHECK(a->workspace_bytes >= (size_t)tiles * a->ksplit * KSPLIT_SLAB_BYTES,
+                  "gemm: split-K workspace of %zu bytes is smaller than %lld tiles x %d slices x %d bytes", a->workspace_bytes, tiles,
+                  a->ksplit, (int)KSPLIT_SLAB_BYTES);
+        // the split-K kernels are VAR = 1: their gather shifts by p.ups (0 | 1) and has no nearest-to-size source map
+        VDX_CHECK(a->upsample != 2, "gemm: split-K does not take the upsample-to-size gather (upsample = 2)");
         switch (a->mode) {
             case VDX_GEMM_PLAIN: return launch_ksplit<0>(p, a->ksplit, (float*)a->workspace, st);
             case VDX_GEMM_CONV3X3: return launch_ksplit<1>(p, a->ksplit, (float*)a->workspace, st);
@@ -573,6 +578,7 @@ extern "C" int vdx_gemm_plan_ksplit(const vdx_gemm_args* a, int32_t* split_row, 
     if (const int rc = gemm_prepare(a, p, geglu, force, ws_family)) return rc;
     *split_row = 0; *ksplit = 0; *workspace_bytes = 0;
     if (ws_family || geglu || force || p.m_begin != 0 || p.M != a->M) return 0;
+    if (a->upsample == 2) return 0;     // no split-K instantiation carries the nearest-to-size gather (vdx_gemm_f16 refuses it)
     const long long rows = p.M;
     const int nt320 = (p.N + 319) / 320, nk = p.K >> 6;
     if (!(nt320 * 320 * 4 <= p.N * 5 && rows >= 1024)) return 0;        // (choose_tile's `fits`: N fills 320-wide tiles)

@@ -48,13 +48,15 @@ def round_up(x: int, m: int) -> int:
 
 
 # --------------------------------------------------------------------------------------------
-_KSPLIT_WS = {}     # device -> fp32 workspace of the split-K tails (grown on demand; launches are stream-ordered)
+_KSPLIT_WS = {}     # (device, stream) -> fp32 workspace of the split-K tails (grown on demand; the slice kernel and its
+                    # reduction are ordered by ONE stream, so two streams must not share slabs)
 
 
 def _ksplit_workspace(device, nbytes):
-    ws = _KSPLIT_WS.get(device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _KSPLIT_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = _KSPLIT_WS[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        ws = _KSPLIT_WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
     return ws
 
 
@@ -164,7 +166,7 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
     # (vdx_gemm_plan; the bits do not depend on the split).  A pinned variant or an explicit row range is left alone.
     spans = [(row_begin, row_end, ksplit)]
     if variant == 0 and row_begin == 0 and row_end == 0 and ksplit == 0 and not wset_rows:
-        key = (M, N, K, mode, geglu, a2 is not None, bias2 is not None, allow_ksplit)      # everything the plan depends on
+        key = (M, N, K, mode, geglu, a2 is not None, bias2 is not None, allow_ksplit, int(g.upsample))      # everything the plan depends on
         plan_ = _PLAN_CACHE.get(key)
         if plan_ is None:
             v_, split_, ks_, wsb_ = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_size_t(0)
@@ -180,9 +182,10 @@ def gemm(a, w, *, M, mode=PLAIN, a2=None, bias=None, bias2=None, rows_per_bias2=
         nt = -(-((row_end or M) - row_begin) // 256) * -(-N // 320)
         wsb = nt * ksplit * 327680
     for rb, re_, ks in spans:
-        g.row_begin, g.row_end, g.ksplit, g.workspace = rb, re_, ks, None
+        g.row_begin, g.row_end, g.ksplit, g.workspace, g.workspace_bytes = rb, re_, ks, None, 0
         if ks > 1:
-            g.workspace = _ksplit_workspace(out.device, wsb).data_ptr()
+            ws_ = _ksplit_workspace(out.device, wsb)
+            g.workspace, g.workspace_bytes = ws_.data_ptr(), ws_.numel() * 4
         if PROFILE is not None:
             rows = (re_ or M) - rb
             name = gemm_kernel_name(rows, N, K, mode, geglu, 7 if wset_rows else variant, single_source=a2 is None and bias2 is None,

@@ -42,6 +42,33 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+# Peer allocations mapped into this process: (peer pid, IPC handle bytes) -> [base pointer, reference count].  HIP refuses
+# to open a handle that is already open, and two stores of one process can export from the same allocator segment, so
+# a mapping is opened once per process and closed when its last store lets go of it.
+_IPC_OPEN: Dict = {}
+
+
+def _ipc_acquire(lib, pid, handle, offset):
+    ent = _IPC_OPEN.get((pid, handle))
+    if ent is None:
+        p = C.c_void_p()
+        if lib.vdx_ipc_open(handle, 0, C.byref(p)) != 0:
+            return None
+        ent = _IPC_OPEN[(pid, handle)] = [p.value, 0]
+    ent[1] += 1
+    return ent[0] + offset
+
+
+def _ipc_release(lib, pid, handle):
+    ent = _IPC_OPEN.get((pid, handle))
+    if ent is None:
+        return
+    ent[1] -= 1
+    if ent[1] <= 0:
+        del _IPC_OPEN[(pid, handle)]
+        lib.vdx_ipc_close(ent[0], 0)
+
+
 class ShardedStore:
     def __init__(self, tensors: Dict[str, torch.Tensor], unit_of: Callable[[str], Optional[str]],
                  schedule: List[str], rank: int, world: int, group=None, comm=None, transport: Optional[str] = None):
@@ -98,7 +125,9 @@ class ShardedStore:
         self._side = torch.cuda.Stream(device=self.device) if self._cuda else None
         self.gathers = 0
         self.transport = "collective"
+        self.peer_self_check = "not run"       # "passed" | "failed" once a world > 1 store has compared peer vs collective
         self._peer_ptrs = None
+        self._opened: List = []                # (peer pid, handle) of every mapping this store holds a reference to
         want = transport or os.environ.get("VDX_SHARD_TRANSPORT") or ("peer" if self._cuda else "collective")
         if want not in ("peer", "collective"):
             raise ValueError(f"unknown shard transport {want!r}")
@@ -126,20 +155,20 @@ class ShardedStore:
                 if r == self.rank:
                     ptrs[r] = self._arena.data_ptr()
                     continue
-                p = C.c_void_p()
-                if lib.vdx_ipc_open(h, o, C.byref(p)) != 0:
+                p = _ipc_acquire(lib, pid, h, o)
+                if p is None:
                     ok = False
                     break
-                ptrs[r] = p.value
-                opened.append((p.value, o))
+                ptrs[r] = p
+                opened.append((pid, h))
         if self.world > 1:       # everybody or nobody
             flags = [None] * self.world
             dist.all_gather_object(flags, ok, group=self.group)
             ok = all(flags)
         if not ok:
-            for p, o in opened:
-                lib.vdx_ipc_close(p, o)
             msg = lib.vdx_last_error()
+            for pid, h in opened:
+                _ipc_release(lib, pid, h)
             warnings.warn(f"ShardedStore: peer mapping of the shard arenas failed ({msg.decode() if msg else 'export failed'}); "
                           "using the collective all-gather")
             return
@@ -162,7 +191,31 @@ class ShardedStore:
             dist.all_gather_object(flags, bool(torch.equal(a, b)), group=self.group)
             if not all(flags):
                 warnings.warn("ShardedStore: the peer-mapped gather does not reproduce the collective one; using the collective all-gather")
-                self.transport = "collective"
+                self._close_peer()
+            self.peer_self_check = "passed" if self.transport == "peer" else "failed"
+
+    def _close_peer(self):
+        """Drop this store's references to the peers' mappings (the last reference closes the mapping) and fall back to
+        the collective transport.  Outstanding copies are waited for first."""
+        if not getattr(self, "_opened", None):      # nothing mapped (world of 1, collective transport, failed setup)
+            return
+        from . import _lib
+        lib = _lib.load()
+        if self._side is not None:
+            self._side.synchronize()
+        for pid, h in self._opened:
+            _ipc_release(lib, pid, h)
+        self._opened, self._peer_ptrs, self.transport = [], None, "collective"
+
+    def close(self):
+        """Release the peer mappings (idempotent).  The store stays usable: gathers then go through the collective."""
+        self._close_peer()
+
+    def __del__(self):
+        try:
+            self._close_peer()
+        except Exception:       # interpreter teardown: the process's mappings go with it
+            pass
 
     def _peer_gather(self, out: torch.Tensor, unit: str):
         from . import _lib

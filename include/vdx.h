@@ -78,6 +78,7 @@ typedef struct vdx_gemm_args {
                              no bias / bias2 / residual / GEGLU                                                    */
     void* workspace;      /* ksplit > 1: >= tiles * ksplit * 327 680 bytes (vdx_gemm_plan_ksplit), 16-byte aligned    */
     const float* wset_bias; /* wset_rows > 0: fp32 [M / wset_rows][N], the initial accumulators                          */
+    size_t workspace_bytes; /* ksplit > 1: the size of `workspace`; the call is refused when the slabs would not fit        */
 } vdx_gemm_args;
 
 int vdx_gemm_f16(const vdx_gemm_args* a, vdx_stream_t stream);

@@ -52,10 +52,28 @@ def main():
         counts[s:e] += 1
     dist.all_reduce(counts)
     assert bool((counts == 1).all()), counts
+    second = None
+    if world > 1 and want_transport == "peer":
+        # a second store in the same process re-uses the peers' mappings (HIP refuses to open an open handle twice), and
+        # close() lets go of them: the last reference closes the mapping
+        from vdx import shard as shard_mod
+        assert m.W.peer_self_check == "passed"
+        m2, _ = build(dev, rank, world)
+        second = m2.W.transport
+        assert second == "peer", second
+        refs = lambda: sum(ent[1] for ent in shard_mod._IPC_OPEN.values())    # noqa: E731
+        assert refs() == 2 * (world - 1), shard_mod._IPC_OPEN      # (one mapping per peer segment, shared by both stores if the arenas share it)
+        dist.barrier()
+        m.W.close()
+        assert m.W.transport == "collective" and refs() == world - 1
+        m2.W.close()
+        m2.W.close()                                              # idempotent
+        assert len(shard_mod._IPC_OPEN) == 0
+        dist.barrier()
     if rank == 0:
         torch.save({"lat": full.cpu(), "ranges": [tuple(r) for r in info["ranges"]], "overlap": info["overlap"],
                     "gathers": getattr(m.W, "gathers", None), "halo_bytes": info2["network_bytes"],
-                    "transport": getattr(m.W, "transport", None)}, out)
+                    "transport": want_transport if world > 1 else getattr(m.W, "transport", None), "second_store": second}, out)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok", flush=True)

@@ -40,7 +40,7 @@ def test_gemm_args_struct_matches_header_field_order():
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void\s*\*|float\s*\*|int32_t)\s*", "", decl)
+        decl = re.sub(r"^(const\s+)?(void\s*\*|float\s*\*|int32_t|size_t)\s*", "", decl)
         names += [n.strip().lstrip("*") for n in decl.split(",")]
     assert names == [f[0] for f in _lib.GemmArgs._fields_]
 
@@ -225,6 +225,40 @@ def test_gemm_plan_is_host_only_and_splits_the_mostly_idle_last_round():
         for k, val in bad.items():
             setattr(g, k, val)
         assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) != 0 and b"rows [" in lib.vdx_last_error(), bad
+
+
+def test_split_k_plan_never_takes_the_upsample_to_size_gather():
+    """the split-K kernels are the VAR = 1 instantiation whose gather shifts by `upsample` (0 | 1); with
+    upsample = 2 (nearest-to-size) they would read the wrong source pixels, in bounds and silently.  vdx_gemm_plan_ksplit
+    must answer "no" for every such convolution (the advisor's case: 48 images 8x22 -> 16x43, N = 640, used to return
+    ksplit = 8 at split_row 32768) and keep answering as before for the same shape without the size map."""
+    import ctypes as C
+    from vdx import _lib
+    lib = _lib.load()
+
+    def plan_ks(n_img, h_in, w_in, h_out, w_out, N, cin, ups):
+        g = _lib.GemmArgs()
+        g.a = g.w = g.out = 1 << 20            # never dereferenced on the host
+        g.M, g.N, g.K, g.mode, g.c1 = n_img * h_out * w_out, N, 9 * cin, 1, cin
+        g.lda, g.ldo = cin, N
+        g.h_in, g.w_in, g.h_out, g.w_out, g.stride, g.upsample = h_in, w_in, h_out, w_out, 1, ups
+        s_, k_, w_ = C.c_int32(-1), C.c_int32(-1), C.c_size_t(1)
+        assert lib.vdx_gemm_plan_ksplit(C.byref(g), C.byref(s_), C.byref(k_), C.byref(w_)) == 0, lib.vdx_last_error()
+        return s_.value, k_.value, w_.value
+
+    assert plan_ks(48, 8, 22, 16, 43, 640, 640, 2) == (0, 0, 0)
+    n = 0
+    for hl, wl in ((16, 43), (17, 33), (33, 129), (21, 21), (50, 100), (129, 16)):
+        for F_ in (8, 12, 16, 24):
+            for B in (1, 2):
+                for lvl, C_ in ((2, 1280), (1, 640)):        # the two upsamplers whose N fills 320-wide tiles on many rows
+                    ho, wo = -(-hl // (1 << lvl)), -(-wl // (1 << lvl))
+                    hi, wi = -(-ho // 2), -(-wo // 2)
+                    assert plan_ks(B * F_, hi, wi, ho, wo, C_, C_, 2)[1] == 0
+                    n += 1
+    assert n == 96
+    # the x2 form of a shape of the same size still plans a split (the check above is not vacuous)
+    assert plan_ks(48, 8, 22, 16, 44, 640, 640, 1)[1] > 1
 
 
 @pytest.mark.parametrize("Fr,rot", [(24, 0), (16, 3), (12, 1), (8, 4), (48, 2)])

@@ -866,6 +866,46 @@ def test_conv3x3_upsample_to_size(gpu, hin, win, hout, wout):
     close(out, ref)
 
 
+def test_split_k_refuses_upsample_to_size_and_short_workspaces(gpu):
+    """A pinned ksplit on the nearest-to-size gather is an error (no split-K instantiation carries the size map: ADVICE r3),
+    and a workspace smaller than tiles x slices x 327 680 bytes is refused instead of overrun.  The automatic path
+    (allow_ksplit) on a to-size convolution large enough for the planner to consider a split gives the un-split result."""
+    ops, packing = _ops()
+    from vdx import _lib
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, hin, win, hout, wout = 2, 64, 320, 5, 8, 9, 15
+    x = h(torch.randn(n, cin, hin, win, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / 24)
+    kw = dict(M=n * hout * wout, mode=ops.CONV3X3, conv=(n, hin, win, hout, wout, 1, 2))
+    xr, wp = packing.nchw_to_rows(x).half().to(gpu), packing.pack_conv3x3(w.half()).to(gpu)
+    with pytest.raises(_lib.VdxError, match="upsample"):
+        ops.gemm(xr, wp, ksplit=2, **kw)
+    ref = packing.nchw_to_rows(F.conv2d(F.interpolate(x, size=(hout, wout), mode="nearest"), w, padding=1))
+    close(ops.gemm(xr, wp, allow_ksplit=True, **kw), ref)
+    # the advisor's shape through the automatic path: 48 images 8x22 -> 16x43, N = 640 (the planner used to split it)
+    n, cin, cout, hin, win, hout, wout = 48, 640, 640, 8, 22, 16, 43
+    x = h(torch.randn(n, cin, hin, win, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / 76)
+    xr, wp = packing.nchw_to_rows(x).half().to(gpu), packing.pack_conv3x3(w.half()).to(gpu)
+    kw = dict(M=n * hout * wout, mode=ops.CONV3X3, conv=(n, hin, win, hout, wout, 1, 2))
+    ref = packing.nchw_to_rows(F.conv2d(F.interpolate(x, size=(hout, wout), mode="nearest"), w, padding=1))
+    out = ops.gemm(xr, wp, allow_ksplit=True, **kw)
+    close(out, ref)
+    assert torch.equal(out, ops.gemm(xr, wp, **kw))
+    # short workspace: the C entry point checks the size it is told
+    import ctypes as C
+    M, N, K = 2048, 320, 1280
+    a = torch.zeros(M, K, dtype=torch.float16, device=gpu)
+    wz = torch.zeros(N, K, dtype=torch.float16, device=gpu)
+    o = torch.empty(M, N, dtype=torch.float16, device=gpu)
+    ws = torch.empty(8 * 2 * 327680 // 4 - 4, dtype=torch.float32, device=gpu)
+    ga = _lib.GemmArgs()
+    ga.a, ga.w, ga.out, ga.M, ga.N, ga.K, ga.c1, ga.lda, ga.ldo = a.data_ptr(), wz.data_ptr(), o.data_ptr(), M, N, K, K, K, N
+    ga.ksplit, ga.workspace, ga.workspace_bytes = 2, ws.data_ptr(), ws.numel() * 4
+    lib = _lib.load()
+    assert lib.vdx_gemm_f16(C.byref(ga), None) != 0 and b"workspace" in lib.vdx_last_error()
+
+
 def test_scheduler_step_uses_the_timesteps_value(gpu):
     """`DDIMScheduler.step` takes the timestep by VALUE (diffusers semantics), also out of sequence: elements of
     `scheduler.timesteps` in any order (recognised by their storage address: no device read), copies of them and a
