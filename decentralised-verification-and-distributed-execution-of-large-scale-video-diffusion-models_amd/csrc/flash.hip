@@ -22,6 +22,30 @@
 // bound at head dim 64, not MFMA bound).
 #include "attn_common.h"
 
+// Diagnostic switches (tools/flash_abl.sh builds them into csrc/build/abl/libflash_<tag>.so; the product defines none):
+//   FL_ABL_NOEXP / NOSUM / NOMAX / NODMA / NOKREAD / NOVREAD / NOS / NOPV / NOBAR   timing-only builds with one part of the
+//       tile removed (WRONG RESULTS by construction) — profiles/r04_flash.md's ablation table;
+//   FL_STAMPS   per-wave s_memtime sums of the tile's phases into g_fl_stamps (read back with vdx_flash_stamps_read).
+#ifdef FL_STAMPS
+static __device__ unsigned long long g_fl_stamps[8 * 32768];     // [block * 4 + wave][8]: issue, S+max, exp+PV, barrier, total, tiles
+#define FL_T(i)                                                     \
+    do {                                                            \
+        __builtin_amdgcn_sched_barrier(0);                          \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        fl_sum[i] += now_ - fl_last;                                \
+        fl_last = now_;                                             \
+        __builtin_amdgcn_sched_barrier(0);                          \
+    } while (0)
+#else
+#define FL_T(i)
+#endif
+// exchange with lane ^ 32 without LDS: v_permlane32_swap of (x, x) leaves the low half's value in a, the high half's in b
+__device__ __forceinline__ float max_xor32(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
 
 struct FlashP {
     const f16 *q, *k, *vt;   // vt: V^T [heads*64][ldvt]  (VROW: V rows [n_kv*skv_pad][ldvt])
@@ -148,9 +172,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     if (CAUSAL) ntiles = min(ntiles, ((qblk + 1) * 4 * 32 * QB + 63) >> 6);   // keys beyond the block's last query: all masked
     issue(0, 0);
     __syncthreads();                       // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
+#ifdef FL_STAMPS
+    unsigned long long fl_sum[4] = {0, 0, 0, 0}, fl_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long fl_first = fl_last;
+#endif
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
+#ifndef FL_ABL_NODMA
         if (t + 1 < ntiles) issue(t + 1, cur ^ 1);   // buffer cur^1 was last read before the previous barrier
+#endif
+        FL_T(0);
         const char* Ks = smem + cur * 16384;
         const char* Vs = Ks + 8192;
         const int k0 = t * 64;
@@ -159,16 +190,41 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         f32x16 s_acc[QB][2], zero16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) zero16[j] = 0.f;
+#ifdef FL_KPRE
+        // all eight K fragments of the tile are requested before the first MFMA: the waits then count down
+        // (lgkmcnt(7) .. (0)) instead of exposing one LDS round trip per pair of MFMAs
+        f16x8 kfa[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int row = kb * 32 + krow, c = 2 * ks + h;
+                kfa[kb][ks] = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int row = kb * 32 + krow;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int c = 2 * ks + h;
+#if defined(FL_KPRE)
+                const f16x8 kf = kfa[kb][ks];
+#elif defined(FL_ABL_NOKREAD)
+                const f16x8 kf = qf[0][(ks + kb) & 3];
+#else
                 const f16x8 kf = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+#endif
+#ifndef FL_ABL_NOS
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], ks == 0 ? zero16 : s_acc[qb][kb], 0, 0, 0);
+#else
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) s_acc[qb][kb][j] = (ks == 0 ? 0.f : s_acc[qb][kb][j]) + (float)kf[j & 7] * (float)qf[qb][ks][j & 7] * (j + 1);
+#endif
             }
             if (offset_on) {
 #pragma unroll
@@ -206,6 +262,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         // overflow there for scores below -128 (0 * inf = NaN).  Tiles far below the running maximum simply
         // underflow to p = 0, as they do in an fp32 softmax.
         bool move[QB], any_move = false;
+#ifndef FL_ABL_NOMAX
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             float m = NEG_BIG;
@@ -213,10 +270,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) m = fmaxf(m, s_acc[qb][kb][j]);
+#ifdef FL_SWAP
+            r_run[qb] = fmaxf(r_run[qb], max_xor32(m));
+            // outside (-4, 10] and not "everything masked so far": |r - 3| > 7, bitwise (no short-circuit branches)
+            move[qb] = (fabsf(r_run[qb] - 3.0f) > 7.0f) & (r_run[qb] > -1.0e29f);
+#else
             r_run[qb] = fmaxf(r_run[qb], fmaxf(m, __shfl_xor(m, 32, 64)));
             move[qb] = r_run[qb] > 10.0f || (r_run[qb] < -4.0f && r_run[qb] > -1.0e29f);   // (all tiles so far masked: nothing to centre on)
+#endif
             any_move |= move[qb];
         }
+#else
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) move[qb] = false;
+#endif
+        FL_T(1);
         if (__builtin_amdgcn_ballot_w64(any_move) != 0) {            // rare
             bool nonzero = false;
 #pragma unroll
@@ -253,9 +321,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 #pragma unroll
                 for (int j = 0; j < 16; j += 2) {
                     f16x2 pp;
+#ifndef FL_ABL_NOEXP
                     pp[0] = (f16)__builtin_amdgcn_exp2f(s_acc[qb][kb][j]);
                     pp[1] = (f16)__builtin_amdgcn_exp2f(s_acc[qb][kb][j + 1]);
+#else
+                    pp[0] = (f16)s_acc[qb][kb][j];
+                    pp[1] = (f16)s_acc[qb][kb][j + 1];
+#endif
+#ifndef FL_ABL_NOSUM
                     l_run[qb] = __builtin_amdgcn_fdot2(pp, one2, l_run[qb], false);
+#endif
                     pf[qb][kb * 2 + (j >> 3)][j & 7] = pp[0];
                     pf[qb][kb * 2 + (j >> 3)][(j & 7) + 1] = pp[1];
                 }
@@ -265,7 +340,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 f16x8 vf;
+#ifdef FL_ABL_NOVREAD
+                vf = qf[0][(kk + db) & 3];
+                if (false) {
+#else
                 if (VROW) {      // keys 16kk + 8h + (0..3 | 4..7) of d = 32db + (lane & 31)
+#endif
                     typedef short s16x4v __attribute__((__vector_size__(8)));
                     typedef __attribute__((address_space(3))) s16x4v* ltr_t;
                     struct TrPair { s16x4v lo, hi; } pr;
@@ -275,15 +355,38 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
                     vf = __builtin_bit_cast(f16x8, pr);
                 } else {
                     const int row = db * 32 + r32;
+#ifndef FL_ABL_NOVREAD
                     vf = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+#endif
                 }
+#ifndef FL_ABL_NOPV
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kk], o_acc[qb][db], 0, 0, 0);
+#else
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o_acc[qb][db][j] += (float)vf[j] * (float)pf[qb][kk][j];
+#endif
             }
         }
+        FL_T(2);
+#ifndef FL_ABL_NOBAR
         __syncthreads();                   // next tile landed (vmcnt(0)) and this one is fully read
+#endif
+        FL_T(3);
     }
+#ifdef FL_STAMPS
+    {
+        const unsigned long long tot = __builtin_amdgcn_s_memtime() - fl_first;
+        if (lane == 0 && blockIdx.x < 8192) {
+            unsigned long long* dst = g_fl_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+            dst[0] = fl_sum[0]; dst[1] = fl_sum[1]; dst[2] = fl_sum[2]; dst[3] = fl_sum[3];
+            dst[4] = tot; dst[5] = (unsigned long long)ntiles;
+        }
+    }
+#endif
 
     // ---- epilogue: O[query][d], lane = query; pair lanes (l, l^32) to emit 16-byte stores ----
 #pragma unroll
@@ -367,3 +470,12 @@ extern "C" int vdx_flash_attn_rows_f16(const void* q, int ldq, const void* k, in
                                        int seq_per_kv, float scale, int causal, vdx_stream_t stream) {
     return flash_launch<true>(q, ldq, k, ldk, v, ldv, out, ldo, n_seq, sq, skv, skv_pad, heads, seq_per_kv, scale, causal, stream);
 }
+
+#ifdef FL_STAMPS
+// diagnostic builds only: the per-wave phase sums of the last launch ([block * 4 + wave][8] x u64, blocks < 8192)
+extern "C" int vdx_flash_stamps_read(void* host, size_t bytes) {
+    VDX_CHECK(host && bytes <= sizeof(g_fl_stamps), "flash_stamps_read: bad buffer");
+    const hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fl_stamps), bytes, 0, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : vdx_fail("flash_stamps_read: %s", hipGetErrorString(e));
+}
+#endif
