@@ -1,9 +1,8 @@
 // flash.hip — flash-style attention on v_mfma_f32_32x32x16_f16: spatial
 // self-attention (seq up to 9216, never materialised) and text cross-attention (77 keys).
 //
-// A wave owns QB sub-blocks of 32 queries (QB = 2: 64 queries per wave, 256 per 4-wave block);
-// K / V^T tiles of 64 keys go through LDS (LDS-DMA staged, double-buffered, one barrier per
-// tile) and every fragment read from LDS feeds QB MFMAs.  Per sub-block:
+// A wave owns QB sub-blocks of 32 queries (QB = 2: 64 queries per wave); K / V tiles of 64 keys go through LDS
+// (LDS-DMA staged) and every fragment read from LDS feeds QB MFMAs.  Per sub-block:
 //   * scores are computed TRANSPOSED, S^T = K.Q^T, so a lane owns ONE query column: the row max is
 //     lane-local plus one exchange with lane^32, and the exponentiated tile is already the B
 //     operand of O^T = V^T.P^T (accumulator-as-operand, no LDS round trip for P).  K rows are fed
@@ -16,18 +15,23 @@
 //     one extra k-step ([1,0,..] row of "K" times [-m,0,..] column of "Q"), so S' = S - m costs one
 //     MFMA per 32 keys and no per-score VALU op, and in the common tile p = exp2(S') directly.
 //     m only has to be the same for a row's p and its row sum, so its fp16 rounding is harmless.
-//   * row sums by v_dot2_f32_f16 against ones.
-// The two sub-blocks are independent instruction streams inside one wave, which is what lets the
-// matrix pipe work on one while the VALU exponentiates the other (the kernel is VALU/latency
-// bound at head dim 64, not MFMA bound).
+//   * row sums by v_dot2_f32_f16 against ones, row maxima by v_max3_f32 — both as FOUR independent chains per
+//     sub-block: a dependent chain of either costs 8.3 cycles per instruction, independent ones 5.3
+//     (tools/micro/coissue.hip, profiles/r04_flash.md).
+// Two kernels share this arithmetic bit for bit:
+//   flash_attn_kernel<QB, CAUSAL, VROW>  256-thread blocks, two per CU: every shape (cross-attention, the CLIP tower,
+//                                        short sequences);
+//   flash_pp_kernel                      512-thread blocks, the two waves of a SIMD in alternating matrix / vector
+//                                        segments (round 4): long self-attention with V as rows — levels 0 and 1.
 #include "attn_common.h"
 
 // Diagnostic switches (tools/flash_abl.sh builds them into csrc/build/abl/libflash_<tag>.so; the product defines none):
-//   FL_ABL_NOEXP / NOSUM / NOMAX / NODMA / NOKREAD / NOVREAD / NOS / NOPV / NOBAR   timing-only builds with one part of the
-//       tile removed (WRONG RESULTS by construction) — profiles/r04_flash.md's ablation table;
-//   FL_STAMPS   per-wave s_memtime sums of the tile's phases into g_fl_stamps (read back with vdx_flash_stamps_read).
+//   FL_ABL_NOEXP / NOSUM / NOMAX / NODMA / NOKREAD / NOVREAD / NOBAR   timing-only builds with one part of the tile
+//       removed (WRONG RESULTS by construction) — profiles/r04_flash.md's ablation table;
+//   FL_STAMPS   per-wave s_memtime sums of the tile's phases into g_fl_stamps (read back with vdx_flash_stamps_read);
+//   FL_PP = 0 | 1   never / always the ping-pong kernel;  FL_PP_PRIO = 0 | 1 | 2   no s_setprio / vector wave / matrix wave.
 #ifdef FL_STAMPS
-static __device__ unsigned long long g_fl_stamps[8 * 32768];     // [block * 4 + wave][8]: issue, S+max, exp+PV, barrier, total, tiles
+static __device__ unsigned long long g_fl_stamps[8 * 32768];     // [block * waves + wave][8]: four phase sums, total, tiles
 #define FL_T(i)                                                     \
     do {                                                            \
         __builtin_amdgcn_sched_barrier(0);                          \
@@ -39,13 +43,6 @@ static __device__ unsigned long long g_fl_stamps[8 * 32768];     // [block * 4 +
 #else
 #define FL_T(i)
 #endif
-// exchange with lane ^ 32 without LDS: v_permlane32_swap of (x, x) leaves the low half's value in a, the high half's in b
-__device__ __forceinline__ float max_xor32(float x) {
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
-}
-
 
 struct FlashP {
     const f16 *q, *k, *vt;   // vt: V^T [heads*64][ldvt]  (VROW: V rows [n_kv*skv_pad][ldvt])
@@ -58,21 +55,27 @@ struct FlashP {
     float c;  // scale * log2(e)
 };
 
-// CAUSAL is a template parameter: the spatial / cross-attention instantiations carry no trace of the mask
-template <int QB, bool CAUSAL, bool VROW>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
-    // LDS: 2 stages x { K tile [64 key][64 d], V^T tile [64 d][64 key] }, 128-B rows,
-    // 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7)  (conflict-free for both reads).
-    // VROW: the second half of a stage is the V tile [64 key][64 d], chunk c of row r at c ^ (4 * ((r >> 1) & 1)):
-    // a transposed read takes 4 key rows x 32 d (64 B) per 32-lane half; rows r, r+1 are 128 B apart (other half of
-    // the 64 banks) and the XOR moves rows r+2, r+3 to the other 64 B of their lines: 32 lanes x 8 B on 64 banks once.
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r32 = lane & 31, h = lane >> 5;
-    // 1-D grid, XCD-aware: blocks L and L+8 share an XCD (and its L2).  All query blocks of one (sequence, head)
-    // pair read the same K / V^T (2.4 MB at 9216 keys), so a pair's blocks are given to ONE XCD (pair = xcd mod 8)
-    // when the pair count divides by 8: its K/V then come from HBM once instead of once per XCD.
-    int pair, qblk;
+typedef const __attribute__((address_space(1))) void* fl_gptr_t;
+typedef __attribute__((address_space(3))) void* fl_lptr_t;
+
+// a wave-uniform pointer the compiler shall keep in SGPRs (folds away when it already is)
+__device__ __forceinline__ const char* fl_uniform(const char* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
+// exchange with lane ^ 32 without LDS: v_permlane32_swap of (x, x) leaves the low half's value in a, the high half's in b
+__device__ __forceinline__ float max_xor32(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+// 1-D grid, XCD-aware: blocks L and L+8 share an XCD (and its L2).  All query blocks of one (sequence, head)
+// pair read the same K / V (2.4 MB at 9216 keys), so a pair's blocks are given to ONE XCD (pair = xcd mod 8)
+// when the pair count divides by 8: its K/V then come from HBM once instead of once per XCD.
+__device__ __forceinline__ void fl_block_map(const FlashP& p, int& pair, int& qblk) {
     if (p.xcd) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         pair = (slot / p.nqb) * 8 + xcd;
@@ -81,12 +84,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
         pair = blockIdx.x / p.nqb;
         qblk = blockIdx.x % p.nqb;
     }
-    const int head = pair % p.heads, seq = pair / p.heads;
-    const int kvb = seq / p.seq_per_kv;
-    const int q0 = (qblk * 4 + wave) * (32 * QB);
+}
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane = query column, pre-scaled --------------
-    f16x8 qf[QB][4];
+// Q fragments (B operand of S^T = K.Q^T): lane = query column, pre-scaled
+template <int QB>
+__device__ __forceinline__ void fl_load_q(const FlashP& p, int seq, int head, int q0, int r32, int h, f16x8 (&qf)[QB][4]) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qr = min(q0 + qb * 32 + r32, p.sq - 1);
@@ -98,211 +100,83 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
             for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (f16)((float)raw[j] * p.c);
         }
     }
+}
 
-    // ---- staging by LDS-DMA (global_load_lds_dwordx4): 2 K pieces + 2 V^T pieces per wave per tile.
-    // Wave-instruction i fills LDS rows (i*256 + wave*64)/8 .. +7 of the tile; lane l lands at row
-    // +(l>>3), 16-byte slot l&7, and therefore fetches data chunk (l&7) ^ ((row>>1)&7).  Source
-    // pointers walk forward one tile per iteration; bounds are only checked in tiles that cross
-    // skv_pad (rows / chunks past it come from the zero page).
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const f16* zp = (const f16*)g_zero_page;
-    const int st_row0 = tid >> 3, st_row1 = st_row0 + 32;             // K key / V^T d row of my piece 0 / 1
-    const int ch0 = (tid & 7) ^ ((st_row0 >> 1) & 7), ch1 = (tid & 7) ^ ((st_row1 >> 1) & 7);
-    const int chv = (tid & 7) ^ (((st_row0 >> 1) & 1) << 2);           // VROW (st_row1 = st_row0 + 32: same swizzle)
-    const f16* kptr0 = p.k + ((size_t)kvb * p.skv_pad + st_row0) * p.ldk + head * 64 + ch0 * 8;
-    const f16* kptr1 = p.k + ((size_t)kvb * p.skv_pad + st_row1) * p.ldk + head * 64 + ch1 * 8;
-    const f16* vptr0 = VROW ? p.vt + ((size_t)kvb * p.skv_pad + st_row0) * p.ldvt + head * 64 + chv * 8
-                            : p.vt + ((size_t)head * 64 + st_row0) * p.ldvt + (size_t)kvb * p.skv_pad + ch0 * 8;
-    const f16* vptr1 = VROW ? p.vt + ((size_t)kvb * p.skv_pad + st_row1) * p.ldvt + head * 64 + chv * 8
-                            : p.vt + ((size_t)head * 64 + st_row1) * p.ldvt + (size_t)kvb * p.skv_pad + ch1 * 8;
-    const size_t kstep = (size_t)64 * p.ldk, vstep = VROW ? (size_t)64 * p.ldvt : 64;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    auto issue = [&](int t, int buf) {
-        char* sk = smem + buf * 16384 + wv * 1024;
-        const int k0 = t * 64;
-        const f16 *k0p = kptr0, *k1p = kptr1, *v0p = vptr0, *v1p = vptr1;
-        if (k0 + 64 > p.skv_pad) {                                    // tile crosses skv_pad (wave-uniform)
-            if (k0 + st_row0 >= p.skv_pad) k0p = zp;
-            if (k0 + st_row1 >= p.skv_pad) k1p = zp;
-            if (VROW) {
-                if (k0 + st_row0 >= p.skv_pad) v0p = zp;
-                if (k0 + st_row1 >= p.skv_pad) v1p = zp;
-            } else {
-                if (k0 + ch0 * 8 >= p.skv_pad) v0p = zp;              // chunks never straddle skv_pad
-                if (k0 + ch1 * 8 >= p.skv_pad) v1p = zp;
-            }
+// The softmax state of a wave's QB sub-blocks and one tile's vector work.
+// The offset m is LAZY and MONOTONE.  r_run is the row's running maximum over all tiles so far, measured against the
+// offset in use.  The offset stays put (and, while it is 0, its MFMA is skipped) as long as r_run lies in (-4, 10]:
+// p = exp2(S') <= 2^10 is exact-enough fp16 with fp32 sums, and a running maximum >= 2^-4 keeps the terms that matter out
+// of fp16 subnormals.  When r_run leaves the window the offset is re-centred ON THE RUNNING maximum (rounded to fp16; only
+// consistency between p and l matters), never on the current tile's: after the first unmasked tile r_run >= -4 always
+// holds, so from then on the offset only RISES (alpha <= 2^-10) and a row moves at most (score range / 10) times.  The one
+// downward move possible is the first one (first tile all below -4): nothing has been accumulated yet, so it rescales
+// nothing (alpha = 1) — exp2(-d) would overflow there for scores below -128 (0 * inf = NaN).  Tiles far below the running
+// maximum simply underflow to p = 0, as they do in an fp32 softmax.
+template <int QB>
+struct FlSoft {
+    float r_run[QB];              // running row maximum relative to the offset in use
+    float l_run[QB][2];           // my half of the row sum, as two partial sums (element pair e of a tile goes to sum e & 1):
+                                  // with the QB sub-blocks interleaved that is four independent dot2c chains
+    f16x8 negm[QB];               // [-m, 0, ...]: the offset's column of "Q" (m: the offset in use, exp2 units, an fp16 number);
+                                  // EVERY lane holds -m in element 0 — the k-step's "K" row e0 is zero for lane half 1, so
+                                  // what half 1 of this operand holds does not matter, and m is read back from here
+    bool offset_on;               // wave-uniform: some row of this wave has a non-zero offset
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            r_run[qb] = NEG_BIG;
+            l_run[qb][0] = l_run[qb][1] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) negm[qb][j] = (f16)0.0f;
         }
-        __builtin_amdgcn_global_load_lds((gptr_t)k0p, (lptr_t)sk, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)k1p, (lptr_t)(sk + 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)v0p, (lptr_t)(sk + 8192), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)v1p, (lptr_t)(sk + 8192 + 4096), 16, 0, 0);
-        kptr0 += kstep;
-        kptr1 += kstep;
-        vptr0 += vstep;
-        vptr1 += vstep;
-    };
-
-    f32x16 o_acc[QB][2];
-    float m_run[QB], r_run[QB], l_run[QB]; // offset in use (exp2 units, fp16-representable); running row maximum relative to it; my half of the row sum
-    f16x8 negm[QB], e0;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        m_run[qb] = l_run[qb] = 0.f;
-        r_run[qb] = NEG_BIG;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o_acc[qb][0][j] = o_acc[qb][1][j] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) negm[qb][j] = (f16)0.0f;
+        offset_on = false;
     }
+    static __device__ __forceinline__ f16x8 e0(int h) {        // [1, 0, ...]: the offset's row of "K"
+        f16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e0[j] = (f16)((j == 0 && h == 0) ? 1.0f : 0.0f);
-    f16x2 one2;
-    one2[0] = one2[1] = (f16)1.0f;
-
-    bool offset_on = false;                // wave-uniform: some row of this wave has a non-zero offset
-    const int krow = pi_row(r32);
-    // VROW: transposed-read address of this lane inside a V tile, for d block 0 / 1.  Lane 4q+p of a 16-lane group
-    // supplies row q, d columns 4p..4p+3 of a block of 4 keys x 16 d and receives column (lane & 15) of the 4 rows:
-    // group (lane >> 4) & 1 takes d 16..31 of the d block, lane half h keys 8h.. of the operand's 16.
-    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
-    const int tr0 = (8 * h + tq) * 128 + (((2 * tg + (tp >> 1)) ^ ((tq >> 1) << 2)) << 4) + 8 * (tp & 1);
-    const int tr1 = tr0 ^ 64;
-    int ntiles = (p.skv + 63) >> 6;
-    if (CAUSAL) ntiles = min(ntiles, ((qblk + 1) * 4 * 32 * QB + 63) >> 6);   // keys beyond the block's last query: all masked
-    issue(0, 0);
-    __syncthreads();                       // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
-#ifdef FL_STAMPS
-    unsigned long long fl_sum[4] = {0, 0, 0, 0}, fl_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long fl_first = fl_last;
-#endif
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-#ifndef FL_ABL_NODMA
-        if (t + 1 < ntiles) issue(t + 1, cur ^ 1);   // buffer cur^1 was last read before the previous barrier
-#endif
-        FL_T(0);
-        const char* Ks = smem + cur * 16384;
-        const char* Vs = Ks + 8192;
-        const int k0 = t * 64;
-
-        // ---- S' = K . Q^T - m : two 32-key blocks, each K fragment feeds QB sub-blocks ------------
-        f32x16 s_acc[QB][2], zero16;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) zero16[j] = 0.f;
-#ifdef FL_KPRE
-        // all eight K fragments of the tile are requested before the first MFMA: the waits then count down
-        // (lgkmcnt(7) .. (0)) instead of exposing one LDS round trip per pair of MFMAs
-        f16x8 kfa[2][4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int row = kb * 32 + krow, c = 2 * ks + h;
-                kfa[kb][ks] = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#endif
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int row = kb * 32 + krow;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int c = 2 * ks + h;
-#if defined(FL_KPRE)
-                const f16x8 kf = kfa[kb][ks];
-#elif defined(FL_ABL_NOKREAD)
-                const f16x8 kf = qf[0][(ks + kb) & 3];
-#else
-                const f16x8 kf = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-#endif
-#ifndef FL_ABL_NOS
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], ks == 0 ? zero16 : s_acc[qb][kb], 0, 0, 0);
-#else
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) s_acc[qb][kb][j] = (ks == 0 ? 0.f : s_acc[qb][kb][j]) + (float)kf[j & 7] * (float)qf[qb][ks][j & 7] * (j + 1);
-#endif
-            }
-            if (offset_on) {
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, negm[qb], s_acc[qb][kb], 0, 0, 0);   // - m
-            }
-        }
-        if (k0 + 64 > p.skv) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (k0 + kb * 32 + acc_key(j, h) >= p.skv) s_acc[qb][kb][j] = NEG_BIG;
-        }
-        if (CAUSAL && k0 + 63 > q0) {                              // tile reaches past this wave's first query
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (k0 + kb * 32 + acc_key(j, h) > q0 + qb * 32 + r32) s_acc[qb][kb][j] = NEG_BIG;
-        }
-        // ---- row maxima.  The offset m is LAZY and MONOTONE.  r_run is the row's running maximum over all
-        // tiles so far, measured against the offset in use.  The offset stays put (and, while it is 0, its
-        // MFMA is skipped) as long as r_run lies in (-4, 10]: p = exp2(S') <= 2^10 is exact-enough fp16 with
-        // fp32 sums, and a running maximum >= 2^-4 keeps the terms that matter out of fp16 subnormals.  When
-        // r_run leaves the window the offset is re-centred ON THE RUNNING maximum (rounded to fp16; only
-        // consistency between p and l matters), never on the current tile's: after the first unmasked tile
-        // r_run >= -4 always holds, so from then on the offset only RISES (alpha <= 2^-10) and a row moves
-        // at most (score range / 10) times.  The one downward move possible is the first one (first tile all
-        // below -4): nothing has been accumulated yet, so it rescales nothing (alpha = 1) — exp2(-d) would
-        // overflow there for scores below -128 (0 * inf = NaN).  Tiles far below the running maximum simply
-        // underflow to p = 0, as they do in an fp32 softmax.
+        for (int j = 0; j < 8; ++j) v[j] = (f16)((j == 0 && h == 0) ? 1.0f : 0.0f);
+        return v;
+    }
+    // s_acc (scores minus the offset in use, masked by the caller) -> pf (fp16 probabilities, the B operand of P.V)
+    __device__ __forceinline__ void tile(f32x16 (&s_acc)[QB][2], f32x16 (&o_acc)[QB][2], f16x8 (&pf)[QB][4], int h) {
         bool move[QB], any_move = false;
 #ifndef FL_ABL_NOMAX
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            float m = NEG_BIG;
+            float mc[4] = {NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};      // four independent v_max3 chains
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) m = fmaxf(m, s_acc[qb][kb][j]);
-#ifdef FL_SWAP
+                for (int j = 0; j < 16; j += 2) mc[(j >> 1) & 3] = fmaxf(fmaxf(mc[(j >> 1) & 3], s_acc[qb][kb][j]), s_acc[qb][kb][j + 1]);
+            const float m = fmaxf(fmaxf(mc[0], mc[1]), fmaxf(mc[2], mc[3]));
             r_run[qb] = fmaxf(r_run[qb], max_xor32(m));
-            // outside (-4, 10] and not "everything masked so far": |r - 3| > 7, bitwise (no short-circuit branches)
+            // outside (-4, 10] and not "every tile so far masked" (nothing to centre on): bitwise, no short-circuit branches
             move[qb] = (fabsf(r_run[qb] - 3.0f) > 7.0f) & (r_run[qb] > -1.0e29f);
-#else
-            r_run[qb] = fmaxf(r_run[qb], fmaxf(m, __shfl_xor(m, 32, 64)));
-            move[qb] = r_run[qb] > 10.0f || (r_run[qb] < -4.0f && r_run[qb] > -1.0e29f);   // (all tiles so far masked: nothing to centre on)
-#endif
             any_move |= move[qb];
         }
 #else
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) move[qb] = false;
 #endif
-        FL_T(1);
         if (__builtin_amdgcn_ballot_w64(any_move) != 0) {            // rare
             bool nonzero = false;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 // the fp16 offset enters the contraction as an MFMA operand: keep it finite (an infinite one
                 // times the zero rows of its k-step would poison every score with NaN)
-                const float tgt = fminf(fmaxf(m_run[qb] + (move[qb] ? r_run[qb] : 0.f), -60000.0f), 60000.0f);
+                const float m_old = -(float)negm[qb][0];
+                const float tgt = fminf(fmaxf(m_old + (move[qb] ? r_run[qb] : 0.f), -60000.0f), 60000.0f);
                 const float m_new = (float)(f16)tgt;
-                const float d = m_new - m_run[qb];                   // shift actually applied
-                m_run[qb] = m_new;
+                const float d = m_new - m_old;                       // shift actually applied
+                negm[qb][0] = (f16)(-m_new);
                 r_run[qb] -= d;
-                negm[qb][0] = (f16)(h == 0 ? -m_new : 0.f);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) s_acc[qb][kb][j] -= d;
                 const float alpha = d > 0.f ? __builtin_amdgcn_exp2f(-d) : 1.0f;   // d < 0: first move, O = l = 0
-                l_run[qb] *= alpha;
+                l_run[qb][0] *= alpha;
+                l_run[qb][1] *= alpha;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     o_acc[qb][0][j] *= alpha;
@@ -312,14 +186,15 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
             }
             offset_on = __builtin_amdgcn_ballot_w64(nonzero) != 0;
         }
-        // ---- p = exp2(S') packed to fp16 pairs, row sums by dot2; O^T += V^T . P^T ------------------
-        f16x8 pf[QB][4];
+        // p = exp2(S') packed to fp16 pairs, row sums by dot2
+        f16x2 one2;
+        one2[0] = one2[1] = (f16)1.0f;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int j = 0; j < 16; j += 2)
 #pragma unroll
-                for (int j = 0; j < 16; j += 2) {
+                for (int qb = 0; qb < QB; ++qb) {
                     f16x2 pp;
 #ifndef FL_ABL_NOEXP
                     pp[0] = (f16)__builtin_amdgcn_exp2f(s_acc[qb][kb][j]);
@@ -329,69 +204,24 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
                     pp[1] = (f16)s_acc[qb][kb][j + 1];
 #endif
 #ifndef FL_ABL_NOSUM
-                    l_run[qb] = __builtin_amdgcn_fdot2(pp, one2, l_run[qb], false);
+                    l_run[qb][(j >> 1) & 1] = __builtin_amdgcn_fdot2(pp, one2, l_run[qb][(j >> 1) & 1], false);
 #endif
                     pf[qb][kb * 2 + (j >> 3)][j & 7] = pp[0];
                     pf[qb][kb * 2 + (j >> 3)][(j & 7) + 1] = pp[1];
                 }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {  // kk = 2*kb + s : keys 16*kk + 8*h .. +7
-            const int c = 2 * kk + h;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                f16x8 vf;
-#ifdef FL_ABL_NOVREAD
-                vf = qf[0][(kk + db) & 3];
-                if (false) {
-#else
-                if (VROW) {      // keys 16kk + 8h + (0..3 | 4..7) of d = 32db + (lane & 31)
-#endif
-                    typedef short s16x4v __attribute__((__vector_size__(8)));
-                    typedef __attribute__((address_space(3))) s16x4v* ltr_t;
-                    struct TrPair { s16x4v lo, hi; } pr;
-                    const char* vb = Vs + (db ? tr1 : tr0) + kk * 2048;
-                    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)vb);
-                    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(vb + 512));
-                    vf = __builtin_bit_cast(f16x8, pr);
-                } else {
-                    const int row = db * 32 + r32;
-#ifndef FL_ABL_NOVREAD
-                    vf = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-#endif
-                }
-#ifndef FL_ABL_NOPV
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kk], o_acc[qb][db], 0, 0, 0);
-#else
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o_acc[qb][db][j] += (float)vf[j] * (float)pf[qb][kk][j];
-#endif
-            }
-        }
-        FL_T(2);
-#ifndef FL_ABL_NOBAR
-        __syncthreads();                   // next tile landed (vmcnt(0)) and this one is fully read
-#endif
-        FL_T(3);
     }
-#ifdef FL_STAMPS
-    {
-        const unsigned long long tot = __builtin_amdgcn_s_memtime() - fl_first;
-        if (lane == 0 && blockIdx.x < 8192) {
-            unsigned long long* dst = g_fl_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
-            dst[0] = fl_sum[0]; dst[1] = fl_sum[1]; dst[2] = fl_sum[2]; dst[3] = fl_sum[3];
-            dst[4] = tot; dst[5] = (unsigned long long)ntiles;
-        }
+    __device__ __forceinline__ float row_sum(int qb) const {
+        const float l = l_run[qb][0] + l_run[qb][1];
+        return l + __shfl_xor(l, 32, 64);
     }
-#endif
+};
 
-    // ---- epilogue: O[query][d], lane = query; pair lanes (l, l^32) to emit 16-byte stores ----
+// epilogue: O[query][d], lane = query; pair lanes (l, l^32) to emit 16-byte stores
+template <int QB>
+__device__ __forceinline__ void fl_store(const FlashP& p, const FlSoft<QB>& st, const f32x16 (&o_acc)[QB][2], int seq, int head, int q0, int r32, int h) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float inv = 1.0f / (l_run[qb] + __shfl_xor(l_run[qb], 32, 64));
+        const float inv = 1.0f / st.row_sum(qb);
         const int qrow = q0 + qb * 32 + r32;
         f16* dst = p.out + ((size_t)seq * p.sq + qrow) * p.ldo + head * 64;
 #pragma unroll
@@ -423,6 +253,532 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     }
 }
 
+// transposed-read address of a lane inside a V tile (VROW), for d block 0; d block 1 = ^ 64.  Lane 4q+p of a 16-lane group
+// supplies row q, d columns 4p..4p+3 of a block of 4 keys x 16 d and receives column (lane & 15) of the 4 rows:
+// group (lane >> 4) & 1 takes d 16..31 of the d block, lane half h keys 8h.. of the operand's 16.
+__device__ __forceinline__ int fl_tr_addr(int lane) {
+    const int h = lane >> 5, tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    return (8 * h + tq) * 128 + (((2 * tg + (tp >> 1)) ^ ((tq >> 1) << 2)) << 4) + 8 * (tp & 1);
+}
+__device__ __forceinline__ f16x8 fl_read_vtr(const char* vb) {      // keys 16kk + 8h + (0..3 | 4..7) of d = 32db + (lane & 31)
+    typedef short s16x4v __attribute__((__vector_size__(8)));
+    typedef __attribute__((address_space(3))) s16x4v* ltr_t;
+    struct TrPair { s16x4v lo, hi; } pr;
+    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)vb);
+    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(vb + 512));
+    return __builtin_bit_cast(f16x8, pr);
+}
+
+// CAUSAL is a template parameter: the spatial / cross-attention instantiations carry no trace of the mask
+template <int QB, bool CAUSAL, bool VROW>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
+    // LDS: 2 stages x { K tile [64 key][64 d], V^T tile [64 d][64 key] }, 128-B rows,
+    // 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7)  (conflict-free for both reads).
+    // VROW: the second half of a stage is the V tile [64 key][64 d], chunk c of row r at c ^ (4 * ((r >> 1) & 1)):
+    // a transposed read takes 4 key rows x 32 d (64 B) per 32-lane half; rows r, r+1 are 128 B apart (other half of
+    // the 64 banks) and the XOR moves rows r+2, r+3 to the other 64 B of their lines: 32 lanes x 8 B on 64 banks once.
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    int pair, qblk;
+    fl_block_map(p, pair, qblk);
+    const int head = pair % p.heads, seq = pair / p.heads;
+    const int kvb = seq / p.seq_per_kv;
+    const int q0 = (qblk * 4 + wave) * (32 * QB);
+
+    f16x8 qf[QB][4];
+    fl_load_q<QB>(p, seq, head, q0, r32, h, qf);
+
+    // ---- staging by LDS-DMA (global_load_lds_dwordx4): 2 K pieces + 2 V^T pieces per wave per tile.
+    // Wave-instruction i fills LDS rows (i*256 + wave*64)/8 .. +7 of the tile; lane l lands at row
+    // +(l>>3), 16-byte slot l&7, and therefore fetches data chunk (l&7) ^ ((row>>1)&7).  Source
+    // pointers walk forward one tile per iteration; bounds are only checked in tiles that cross
+    // skv_pad (rows / chunks past it come from the zero page).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const f16* zp = (const f16*)g_zero_page;
+    const int st_row0 = tid >> 3, st_row1 = st_row0 + 32;             // K key / V^T d row of my piece 0 / 1
+    const int ch0 = (tid & 7) ^ ((st_row0 >> 1) & 7), ch1 = (tid & 7) ^ ((st_row1 >> 1) & 7);
+    const int chv = (tid & 7) ^ (((st_row0 >> 1) & 1) << 2);           // VROW (st_row1 = st_row0 + 32: same swizzle)
+    const f16* kptr0 = p.k + ((size_t)kvb * p.skv_pad + st_row0) * p.ldk + head * 64 + ch0 * 8;
+    const f16* kptr1 = p.k + ((size_t)kvb * p.skv_pad + st_row1) * p.ldk + head * 64 + ch1 * 8;
+    const f16* vptr0 = VROW ? p.vt + ((size_t)kvb * p.skv_pad + st_row0) * p.ldvt + head * 64 + chv * 8
+                            : p.vt + ((size_t)head * 64 + st_row0) * p.ldvt + (size_t)kvb * p.skv_pad + ch0 * 8;
+    const f16* vptr1 = VROW ? p.vt + ((size_t)kvb * p.skv_pad + st_row1) * p.ldvt + head * 64 + chv * 8
+                            : p.vt + ((size_t)head * 64 + st_row1) * p.ldvt + (size_t)kvb * p.skv_pad + ch1 * 8;
+    const size_t kstep = (size_t)64 * p.ldk, vstep = VROW ? (size_t)64 * p.ldvt : 64;
+    auto issue = [&](int t, int buf) {
+        char* sk = smem + buf * 16384 + wv * 1024;
+        const int k0 = t * 64;
+        const f16 *k0p = kptr0, *k1p = kptr1, *v0p = vptr0, *v1p = vptr1;
+        if (k0 + 64 > p.skv_pad) {                                    // tile crosses skv_pad (wave-uniform)
+            if (k0 + st_row0 >= p.skv_pad) k0p = zp;
+            if (k0 + st_row1 >= p.skv_pad) k1p = zp;
+            if (VROW) {
+                if (k0 + st_row0 >= p.skv_pad) v0p = zp;
+                if (k0 + st_row1 >= p.skv_pad) v1p = zp;
+            } else {
+                if (k0 + ch0 * 8 >= p.skv_pad) v0p = zp;              // chunks never straddle skv_pad
+                if (k0 + ch1 * 8 >= p.skv_pad) v1p = zp;
+            }
+        }
+        __builtin_amdgcn_global_load_lds((fl_gptr_t)k0p, (fl_lptr_t)sk, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((fl_gptr_t)k1p, (fl_lptr_t)(sk + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((fl_gptr_t)v0p, (fl_lptr_t)(sk + 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((fl_gptr_t)v1p, (fl_lptr_t)(sk + 8192 + 4096), 16, 0, 0);
+        kptr0 += kstep;
+        kptr1 += kstep;
+        vptr0 += vstep;
+        vptr1 += vstep;
+    };
+
+    f32x16 o_acc[QB][2];
+    FlSoft<QB> st;
+    st.init();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o_acc[qb][0][j] = o_acc[qb][1][j] = 0.f;
+
+    const f16x8 e0 = FlSoft<QB>::e0(h);
+    const int krow = pi_row(r32);
+    const int tr0 = fl_tr_addr(lane), tr1 = tr0 ^ 64;
+    int ntiles = (p.skv + 63) >> 6;
+    if (CAUSAL) ntiles = min(ntiles, ((qblk + 1) * 4 * 32 * QB + 63) >> 6);   // keys beyond the block's last query: all masked
+    issue(0, 0);
+    __syncthreads();                       // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
+#ifdef FL_STAMPS
+    unsigned long long fl_sum[4] = {0, 0, 0, 0}, fl_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long fl_first = fl_last;
+#endif
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+#ifndef FL_ABL_NODMA
+        if (t + 1 < ntiles) issue(t + 1, cur ^ 1);   // buffer cur^1 was last read before the previous barrier
+#endif
+        FL_T(0);
+        const char* Ks = smem + cur * 16384;
+        const char* Vs = Ks + 8192;
+        const int k0 = t * 64;
+
+        // ---- S' = K . Q^T - m : two 32-key blocks, each K fragment feeds QB sub-blocks ------------
+        f32x16 s_acc[QB][2], zero16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) zero16[j] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int row = kb * 32 + krow;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + h;
+#if defined(FL_ABL_NOKREAD)
+                const f16x8 kf = qf[0][(ks + kb) & 3];
+#else
+                const f16x8 kf = *(const f16x8*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+#endif
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], ks == 0 ? zero16 : s_acc[qb][kb], 0, 0, 0);
+            }
+            if (st.offset_on) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, st.negm[qb], s_acc[qb][kb], 0, 0, 0);   // - m
+            }
+        }
+        if (k0 + 64 > p.skv) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (k0 + kb * 32 + acc_key(j, h) >= p.skv) s_acc[qb][kb][j] = NEG_BIG;
+        }
+        if (CAUSAL && k0 + 63 > q0) {                              // tile reaches past this wave's first query
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (k0 + kb * 32 + acc_key(j, h) > q0 + qb * 32 + r32) s_acc[qb][kb][j] = NEG_BIG;
+        }
+        FL_T(1);
+        // ---- row maxima, p = exp2(S') packed to fp16 pairs, row sums; O^T += V^T . P^T ------------------
+        f16x8 pf[QB][4];
+        st.tile(s_acc, o_acc, pf, h);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {  // kk = 2*kb + s : keys 16*kk + 8*h .. +7
+            const int c = 2 * kk + h;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                f16x8 vf;
+#ifdef FL_ABL_NOVREAD
+                vf = qf[0][(kk + db) & 3];
+#else
+                if (VROW) {
+                    vf = fl_read_vtr(Vs + (db ? tr1 : tr0) + kk * 2048);
+                } else {
+                    const int row = db * 32 + r32;
+                    vf = *(const f16x8*)(Vs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
+#endif
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kk], o_acc[qb][db], 0, 0, 0);
+            }
+        }
+        FL_T(2);
+#ifndef FL_ABL_NOBAR
+        __syncthreads();                   // next tile landed (vmcnt(0)) and this one is fully read
+#endif
+        FL_T(3);
+    }
+#ifdef FL_STAMPS
+    {
+        const unsigned long long tot = __builtin_amdgcn_s_memtime() - fl_first;
+        if (lane == 0 && blockIdx.x < 8192) {
+            unsigned long long* dst = g_fl_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+            dst[0] = fl_sum[0]; dst[1] = fl_sum[1]; dst[2] = fl_sum[2]; dst[3] = fl_sum[3];
+            dst[4] = tot; dst[5] = (unsigned long long)ntiles;
+        }
+    }
+#endif
+    fl_store<QB>(p, st, o_acc, seq, head, q0, r32, h);
+}
+
+// ---- the ping-pong form (round 4): long self-attention, V as rows ------------------------------------------------------
+// What profiles/r04_flash.md found in the kernel above (level 0, 5.15 ms): its time is the SUM of its parts — timing-only
+// builds without exp -13 %, without row max -9 %, without row sums -4 %, without DMA -9 %, without K reads -7 %, the MFMAs
+// alone 63 % — because the vector port of a SIMD serves its two waves one instruction at a time (v_exp_f32 8.6 cycles,
+// everything else 4.9-5.3, a DEPENDENT max3 / dot2c chain 8.3; an MFMA takes the port for a few cycles of its 32), and
+// because a wave streaming MFMAs that is older (or has priority) lets its partner issue one vector instruction per MFMA:
+// two identical waves drift into the same phase and wait for the same pipe (tools/micro/coissue.hip).
+// Here the pairing is explicit.  A block is 512 threads; waves w and w + 4 share a SIMD; a workgroup barrier separates
+// PHASES in which one of them is in its MATRIX segment (S of tile i and P.V of tile i - 1: 32 MFMAs and their LDS fragment
+// reads in a fixed software pipeline, nothing else) while the other is in its VECTOR segment (softmax of its tile, and its
+// share of the LDS-DMA of a later tile).  Waves 4-7 run one phase behind waves 0-3.  All eight waves read the same K / V
+// tiles (512 queries per block: half the DMA instructions and LDS writes per query) through a ring of four 16 KB tiles:
+//   interval b = between workgroup barriers b and b + 1;  group X = waves 0-3, Y = waves 4-7
+//   X: matrix(i) in interval 1 + 2i, vector(i) in 2 + 2i;  Y: matrix(i) in 2 + 2i, vector(i) in 3 + 2i
+//   matrix(i) reads K(i), V(i - 1) and opens with the wave's LDS-DMA: X issues V(i + 2), Y issues K(i + 3)  (tiles 0, 1
+//   and K(2) come from the prologue): a slot is rewritten one interval after its last reader; the issuing wave waits for
+//   its DMA at the head of its NEXT matrix segment (a whole tile period in flight: the barriers carry no fence), whose
+//   closing barrier publishes the tile one interval before its first reader.
+// Arithmetic, operand layouts and the order of every sum are those of the kernel above: the bits are identical.
+// A plain workgroup barrier: no fence, so LDS-DMA a wave has in flight stays in flight across it (what it must have
+// finished is waited for with flpp_wait_vm in front).  The compiler may move nothing across it.
+#define FLPP_BAR()                                      \
+    do {                                                \
+        __builtin_amdgcn_sched_barrier(0);              \
+        asm volatile("s_barrier" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);              \
+    } while (0)
+template <int N>
+__device__ __forceinline__ void flpp_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS fragment reads of the matrix segment as inline asm with COUNTED waits.  Two reasons: hipcc puts s_waitcnt vmcnt(0) in
+// front of a ds_read_b64_tr_b16 that follows an LDS-DMA it cannot tell apart (the wave's DMA of a LATER tile would be waited
+// for in the middle of the matrix segment), and it sinks reads towards their use.  LDS operations complete in issue order
+// and the segment issues nothing else that counts in lgkmcnt, so "all but the N youngest" is exact; a wait takes the
+// fragment as an in/out operand so that the MFMAs that consume it cannot be scheduled in front of it.
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const char* fl_lds_t;
+template <int OFF_BYTES>
+__device__ __forceinline__ void flpp_ds_read_b128(f16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF_BYTES));
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ void flpp_ds_read_tr(u32x2v& lo, u32x2v& hi, unsigned addr) {      // one V^T operand: 2 x 8 bytes
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr), "n"(OFF_BYTES), "n"(OFF_BYTES + 512));
+}
+template <int N>
+__device__ __forceinline__ void flpp_wait_lgkm(f16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void flpp_wait_lgkm(u32x2v& lo, u32x2v& hi) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N));
+}
+__device__ __forceinline__ f16x8 flpp_frag(const u32x2v& lo, const u32x2v& hi) {
+    struct { u32x2v lo, hi; } pr = {lo, hi};
+    return __builtin_bit_cast(f16x8, pr);
+}
+// LDS byte offset of this lane's K fragment 0 of keys 0-31 inside a tile: row krow, chunk h ^ swizzle; fragment ks is the
+// chunk (2 ks + h) ^ swizzle = this address ^ (ks << 5) (tile bases are multiples of 128); keys 32-63: + 4096
+__device__ __forceinline__ unsigned flpp_k_addr(int krow, int h) {
+    return (unsigned)(krow * 128 + ((h ^ ((krow >> 1) & 7)) << 4));
+}
+
+// K fragments of keys 0-31 of a tile: requested at the END of the vector segment in front of the matrix segment that uses
+// them (the tile has been visible for an interval by then), so that no LDS latency opens the matrix segment.  They are
+// the only LDS operations outstanding when that matrix segment starts.
+__device__ __forceinline__ void flpp_read_k0(unsigned tile_base, unsigned ka, f16x8 (&kf0)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) flpp_ds_read_b128<0>(kf0[ks], (tile_base + ka) ^ (ks << 5));
+}
+
+// One matrix segment, straight-line, in a fixed order; `n` = LDS reads outstanding, oldest first:
+//   entry: K0[0..3] (n = 4)            issue K1[0..3] (keys 32-63)                     n = 8
+//   4 x { wait K0[ks] ; 2 S MFMAs }                                                    n = 4       (+ 2 offset MFMAs when OFF)
+//   4 x { wait K1[ks] ; 2 S MFMAs ; issue V operand ks (2 reads) }                     n = 5 .. 8  (+ 2 offset MFMAs)
+//   4 x { wait V[f]   ; 2 P.V MFMAs ; issue V operand 4 + f }                          n = 8
+//   4 x { wait V[4+f] ; 2 P.V MFMAs }                                                  n = 6, 4, 2, 0
+// every fragment is requested at least four MFMAs (128 cycles) before its wait.
+template <bool DO_S, bool DO_PV>
+__device__ __forceinline__ void flpp_matrix(bool OFF, unsigned k_base, unsigned v_base, unsigned ka, unsigned tr0, unsigned tr1,
+                                            int h, const f16x8 (&qf)[2][4], const f16x8 (&pf)[2][4], f16x8 (&kf0)[4], const FlSoft<2>& st,
+                                            f32x16 (&s_acc)[2][2], f32x16 (&o_acc)[2][2]) {
+    f32x16 zero16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) zero16[j] = 0.f;
+    f16x8 kf1[4];
+    u32x2v vlo[8], vhi[8];
+#define FLPP_SB() __builtin_amdgcn_sched_barrier(0)
+#define FLPP_MM_S(KB, KS, KF)                                                                                                          \
+    do {                                                                                                                               \
+        s_acc[0][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(KF, qf[0][KS], KS == 0 ? zero16 : s_acc[0][KB], 0, 0, 0);                 \
+        s_acc[1][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(KF, qf[1][KS], KS == 0 ? zero16 : s_acc[1][KB], 0, 0, 0);                 \
+    } while (0)
+#define FLPP_MM_OFF(KB)                                                                                                                \
+    do {                                                                                                                               \
+        f16x8 e0 = FlSoft<2>::e0(h);         /* built here (4 moves): four registers that need not live through the loop */            \
+        asm volatile("" : "+v"(e0));                                                                                                   \
+        s_acc[0][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, st.negm[0], s_acc[0][KB], 0, 0, 0);                                   \
+        s_acc[1][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, st.negm[1], s_acc[1][KB], 0, 0, 0);                                   \
+    } while (0)
+#define FLPP_MM_PV(F)                                                                                                                  \
+    do {                                                                                                                               \
+        const f16x8 vf_ = flpp_frag(vlo[F], vhi[F]);                                                                                   \
+        o_acc[0][(F) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_, pf[0][(F) >> 1], o_acc[0][(F) & 1], 0, 0, 0);                   \
+        o_acc[1][(F) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_, pf[1][(F) >> 1], o_acc[1][(F) & 1], 0, 0, 0);                   \
+    } while (0)
+    // V operand f = 2 kk + db: bytes kk * 2048 of the V tile, transposed-read address tr0 (db 0) | tr1 (db 1)
+#define FLPP_RD_V(F) flpp_ds_read_tr<((F) >> 1) * 2048>(vlo[F], vhi[F], v_base + (((F) & 1) ? tr1 : tr0))
+    FLPP_SB();
+    if (DO_S) {
+        flpp_ds_read_b128<4096>(kf1[0], k_base + ka);
+        flpp_ds_read_b128<4096>(kf1[1], (k_base + ka) ^ 32);
+        flpp_ds_read_b128<4096>(kf1[2], (k_base + ka) ^ 64);
+        flpp_ds_read_b128<4096>(kf1[3], (k_base + ka) ^ 96);
+        FLPP_SB();
+        flpp_wait_lgkm<7>(kf0[0]); FLPP_MM_S(0, 0, kf0[0]); FLPP_SB();
+        flpp_wait_lgkm<6>(kf0[1]); FLPP_MM_S(0, 1, kf0[1]); FLPP_SB();
+        flpp_wait_lgkm<5>(kf0[2]); FLPP_MM_S(0, 2, kf0[2]); FLPP_SB();
+        flpp_wait_lgkm<4>(kf0[3]); FLPP_MM_S(0, 3, kf0[3]); FLPP_SB();
+        if (OFF) { FLPP_MM_OFF(0); }          // (wave-uniform branch)
+        FLPP_SB();
+        if (DO_PV) {
+            flpp_wait_lgkm<3>(kf1[0]); FLPP_MM_S(1, 0, kf1[0]); FLPP_SB(); FLPP_RD_V(0); FLPP_SB();      // outstanding: K1[1..3] V0      = 5
+            flpp_wait_lgkm<4>(kf1[1]); FLPP_MM_S(1, 1, kf1[1]); FLPP_SB(); FLPP_RD_V(1); FLPP_SB();      // K1[2..3] V0 V1               = 6
+            flpp_wait_lgkm<5>(kf1[2]); FLPP_MM_S(1, 2, kf1[2]); FLPP_SB(); FLPP_RD_V(2); FLPP_SB();      // K1[3] V0 V1 V2               = 7
+            flpp_wait_lgkm<6>(kf1[3]); FLPP_MM_S(1, 3, kf1[3]); FLPP_SB(); FLPP_RD_V(3); FLPP_SB();      // V0 .. V3                     = 8
+        } else {
+            flpp_wait_lgkm<3>(kf1[0]); FLPP_MM_S(1, 0, kf1[0]); FLPP_SB();
+            flpp_wait_lgkm<2>(kf1[1]); FLPP_MM_S(1, 1, kf1[1]); FLPP_SB();
+            flpp_wait_lgkm<1>(kf1[2]); FLPP_MM_S(1, 2, kf1[2]); FLPP_SB();
+            flpp_wait_lgkm<0>(kf1[3]); FLPP_MM_S(1, 3, kf1[3]); FLPP_SB();
+        }
+        if (OFF) { FLPP_MM_OFF(1); }
+        FLPP_SB();
+    } else {
+        FLPP_RD_V(0); FLPP_RD_V(1); FLPP_RD_V(2); FLPP_RD_V(3);
+        FLPP_SB();
+    }
+    if (DO_PV) {
+        flpp_wait_lgkm<6>(vlo[0], vhi[0]); FLPP_MM_PV(0); FLPP_SB(); FLPP_RD_V(4); FLPP_SB();
+        flpp_wait_lgkm<6>(vlo[1], vhi[1]); FLPP_MM_PV(1); FLPP_SB(); FLPP_RD_V(5); FLPP_SB();
+        flpp_wait_lgkm<6>(vlo[2], vhi[2]); FLPP_MM_PV(2); FLPP_SB(); FLPP_RD_V(6); FLPP_SB();
+        flpp_wait_lgkm<6>(vlo[3], vhi[3]); FLPP_MM_PV(3); FLPP_SB(); FLPP_RD_V(7); FLPP_SB();
+        flpp_wait_lgkm<6>(vlo[4], vhi[4]); FLPP_MM_PV(4); FLPP_SB();
+        flpp_wait_lgkm<4>(vlo[5], vhi[5]); FLPP_MM_PV(5); FLPP_SB();
+        flpp_wait_lgkm<2>(vlo[6], vhi[6]); FLPP_MM_PV(6); FLPP_SB();
+        flpp_wait_lgkm<0>(vlo[7], vhi[7]); FLPP_MM_PV(7); FLPP_SB();
+    }
+#undef FLPP_SB
+#undef FLPP_MM_S
+#undef FLPP_MM_OFF
+#undef FLPP_MM_PV
+#undef FLPP_RD_V
+}
+
+__global__ __launch_bounds__(512) void flash_pp_kernel(const FlashP p) {
+    constexpr int QB = 2;
+    __shared__ __attribute__((aligned(128))) char smem[4 * 16384];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
+    const int r32 = lane & 31, h = lane >> 5;
+    int pair, qblk;
+    fl_block_map(p, pair, qblk);
+    const int head = pair % p.heads, seq = pair / p.heads;
+    const int kvb = seq / p.seq_per_kv;
+    const int q0 = (qblk * 8 + wave) * 64;
+
+    f16x8 qf[QB][4];
+    fl_load_q<QB>(p, seq, head, q0, r32, h, qf);
+
+    // ---- staging: a K or V half tile (8 KB) = 2 instructions of a 4-wave group; lane l of wave gw fills LDS row
+    // i * 32 + gw * 8 + (l >> 3), 16-byte slot l & 7, swizzles as in the kernel above.  A source address is a wave-uniform
+    // base (SGPRs: tensor + head + tile, advanced per tile by scalar adds) + ONE 32-bit lane offset (row st_row0, swizzled
+    // chunk; the second piece is 32 rows further: the same swizzle, a uniform distance) — global_load_lds's saddr form.
+    const char* zp = (const char*)g_zero_page;
+    const int st_row0 = gtid >> 3, st_row1 = st_row0 + 32;
+    const int ch0 = (gtid & 7) ^ ((st_row0 >> 1) & 7);                 // (row + 32: the same swizzle)
+    const int chv = (gtid & 7) ^ (((st_row0 >> 1) & 1) << 2);
+    const char* kbase = (const char*)(p.k + (size_t)kvb * p.skv_pad * p.ldk + head * 64);
+    const char* vbase = (const char*)(p.vt + (size_t)kvb * p.skv_pad * p.ldvt + head * 64);
+    const unsigned koff = (unsigned)(st_row0 * p.ldk + ch0 * 8) * 2u, voff = (unsigned)(st_row0 * p.ldvt + chv * 8) * 2u;
+    const size_t kstep = (size_t)128 * p.ldk, vstep = (size_t)128 * p.ldvt;     // bytes per tile of 64 rows
+    const int ntiles = (p.skv + 63) >> 6;
+    // `base`: uniform address of the tile's first row; off: my lane offset; half: bytes of 32 rows
+    auto issue_half = [&](const char* base, unsigned off, size_t half, int t, int v_half) __attribute__((always_inline)) {
+        char* dst = smem + (t & 3) * 16384 + v_half * 8192 + gw * 1024;
+        const int k0 = t * 64;
+        if (k0 + 64 > p.skv_pad) {                                    // tile crosses skv_pad (wave-uniform, last tile only):
+            const char* s0 = k0 + st_row0 >= p.skv_pad ? zp : base + off;          // rows past it come from the zero page
+            const char* s1 = k0 + st_row1 >= p.skv_pad ? zp : base + half + off;
+            __builtin_amdgcn_global_load_lds((fl_gptr_t)s0, (fl_lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((fl_gptr_t)s1, (fl_lptr_t)(dst + 4096), 16, 0, 0);
+        } else {
+            const char *b0 = fl_uniform(base), *b1 = fl_uniform(base + half);   // SGPR pairs: the saddr form, one lane-offset VGPR
+            __builtin_amdgcn_global_load_lds((fl_gptr_t)(b0 + off), (fl_lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((fl_gptr_t)(b1 + off), (fl_lptr_t)(dst + 4096), 16, 0, 0);
+        }
+    };
+    // prologue: X stages K(0), V(0), V(1); Y stages K(1), K(2)
+    if (grp == 0) {
+        issue_half(kbase, koff, kstep / 2, 0, 0);
+        issue_half(vbase, voff, vstep / 2, 0, 1);
+        if (1 < ntiles) issue_half(vbase + vstep, voff, vstep / 2, 1, 1);
+    } else {
+        if (1 < ntiles) issue_half(kbase + kstep, koff, kstep / 2, 1, 0);
+        if (2 < ntiles) issue_half(kbase + 2 * kstep, koff, kstep / 2, 2, 0);
+    }
+    // my group's running source of the steady state: X streams V from tile 2, Y streams K from tile 3
+    const char* rbase = grp == 0 ? vbase + 2 * vstep : kbase + 3 * kstep;
+    const unsigned roff = grp == 0 ? voff : koff;
+    const size_t rstep = grp == 0 ? vstep : kstep;
+    const int rlead = grp == 0 ? 2 : 3;
+
+    f32x16 o_acc[QB][2], s_acc[QB][2];
+    f16x8 pf[QB][4];
+    FlSoft<QB> st;
+    st.init();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o_acc[qb][0][j] = o_acc[qb][1][j] = 0.f;
+    const int krow = pi_row(r32);
+    const unsigned lds0 = (unsigned)(size_t)(fl_lds_t)smem;      // LDS byte address of the ring
+    const unsigned ka = flpp_k_addr(krow, h);
+    const unsigned tr0 = (unsigned)fl_tr_addr(lane), tr1 = tr0 ^ 64;
+
+    flpp_wait_vm<0>();
+    FLPP_BAR();                            // barrier 0: the prologue's tiles have landed
+    if (grp == 1) FLPP_BAR();              // Y sits out interval 0
+    f16x8 kf0[4];
+    flpp_read_k0(lds0, ka, kf0);
+#ifdef FL_STAMPS
+    unsigned long long fl_sum[4] = {0, 0, 0, 0}, fl_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long fl_first = fl_last;
+#endif
+    // vector segment of tile i: my share of the DMA, then softmax(i): s_acc -> pf, l_run
+    auto vector_segment = [&](int i) __attribute__((always_inline)) {
+#if !defined(FL_PP_PRIO) || FL_PP_PRIO == 1
+        // tools/micro/coissue.hip: a wave that streams MFMAs and is the older one (or has the priority) lets its SIMD
+        // partner issue ONE vector instruction per MFMA (32-40 cycles each); with the priority on the vector wave both
+        // run at their own rate (v_exp 10.4 instead of 8.6 cycles, an MFMA every 32.4)
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        const int k0 = i * 64;
+        if (k0 + 64 > p.skv) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (k0 + kb * 32 + acc_key(j, h) >= p.skv) s_acc[qb][kb][j] = NEG_BIG;
+        }
+        st.tile(s_acc, o_acc, pf, h);
+        if (i + 1 < ntiles) flpp_read_k0(lds0 + ((i + 1) & 3) * 16384, ka, kf0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // my share of the LDS-DMA, at the head of a MATRIX segment (an LDS-DMA instruction holds its wave for 100-170 cycles —
+    // profiles/r04_flash.md — which the matrix segment can afford and the vector segment, the longer one, cannot): first
+    // wait for what I issued one tile period ago — the barrier that ends this segment then publishes it
+    auto dma_segment = [&](int i) __attribute__((always_inline)) {
+        flpp_wait_vm<0>();
+#ifndef FL_ABL_NODMA
+        if (i + rlead < ntiles) issue_half(rbase, roff, rstep / 2, i + rlead, grp ^ 1);
+#endif
+        rbase += rstep;
+    };
+    // ---- tile 0: S only
+    dma_segment(0);
+    flpp_matrix<true, false>(false, lds0, lds0, ka, tr0, tr1, h, qf, pf, kf0, st, s_acc, o_acc);
+    FLPP_BAR();
+    vector_segment(0);
+    FLPP_BAR();
+    for (int i = 1; i < ntiles; ++i) {
+        // ================= matrix segment: S(i) = K(i).Q^T - m, O^T += V(i-1)^T.P(i-1)^T =================
+        const unsigned Ks = lds0 + (i & 3) * 16384, Vs = lds0 + ((i - 1) & 3) * 16384 + 8192;
+#ifdef FL_PP_SOLO      // (diagnostic: waves 4-7 only keep the barriers company — the segments' lengths without a SIMD partner)
+        if (grp == 0)
+#endif
+        {
+        dma_segment(i);
+        flpp_matrix<true, true>(st.offset_on, Ks, Vs, ka, tr0, tr1, h, qf, pf, kf0, st, s_acc, o_acc);
+        }
+        FL_T(0);
+        FLPP_BAR();
+        FL_T(1);
+#ifdef FL_PP_SOLO
+        if (grp == 0)
+#endif
+        vector_segment(i);
+        FL_T(2);
+        FLPP_BAR();
+#if defined(FL_PP_PRIO) && FL_PP_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);       // (diagnostic: the priority on the MATRIX wave instead)
+#endif
+        FL_T(3);
+    }
+    // ---- P.V of the last tile
+    flpp_wait_vm<0>();
+    flpp_matrix<false, true>(false, lds0, lds0 + ((ntiles - 1) & 3) * 16384 + 8192, ka, tr0, tr1, h, qf, pf, kf0, st, s_acc, o_acc);
+    FLPP_BAR();
+    FLPP_BAR();
+#ifdef FL_STAMPS
+    {
+        const unsigned long long tot = __builtin_amdgcn_s_memtime() - fl_first;
+        if (lane == 0 && blockIdx.x < 4096) {
+            unsigned long long* dst = g_fl_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+            dst[0] = fl_sum[0]; dst[1] = fl_sum[1]; dst[2] = fl_sum[2]; dst[3] = fl_sum[3];
+            dst[4] = tot; dst[5] = (unsigned long long)ntiles - 1;
+        }
+    }
+#endif
+    if (grp == 0) FLPP_BAR();              // X sits out the last interval (Y's matrix(ntiles))
+    fl_store<QB>(p, st, o_acc, seq, head, q0, r32, h);
+}
+
+// The ping-pong kernel's tiles are 512 queries: taken when the last block of a sequence is at least 3/4 full (9216, 2304
+// tokens) and there are enough K/V tiles to amortise its prologue.  FL_PP = 0 | 1 (diagnostic builds) overrides.
+static bool flash_pp_wanted(int sq, int skv) {
+#if defined(FL_PP)
+    return FL_PP != 0 && skv >= 256;
+#else
+    const int last = sq % 512;
+    return sq >= 2048 && skv >= 1024 && (last == 0 || last >= 256);
+#endif
+}
+
 template <bool VROW>
 static int flash_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                         void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
@@ -445,6 +801,13 @@ static int flash_launch(const void* q, int ldq, const void* k, int ldk, const vo
     p.heads = heads;
     p.npairs = n_seq * heads;
     p.xcd = p.npairs % 8 == 0 ? 1 : 0;
+    // the ping-pong form (512 queries per block): long self-attention with V as rows, when padding sq to 512 wastes little
+    if (VROW && !causal && flash_pp_wanted(sq, skv)) {
+        p.nqb = (sq + 511) / 512;
+        VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
+        hipLaunchKernelGGL(flash_pp_kernel, dim3(p.nqb * p.npairs), dim3(512), 0, (hipStream_t)stream, p);
+        return vdx_launch_status("vdx_flash_attn_rows_f16");
+    }
     p.nqb = two ? (sq + 255) / 256 : (sq + 127) / 128;
     VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
     if (two) {
@@ -472,7 +835,7 @@ extern "C" int vdx_flash_attn_rows_f16(const void* q, int ldq, const void* k, in
 }
 
 #ifdef FL_STAMPS
-// diagnostic builds only: the per-wave phase sums of the last launch ([block * 4 + wave][8] x u64, blocks < 8192)
+// diagnostic builds only: the per-wave phase sums of the last launch ([block * waves + wave][8] x u64)
 extern "C" int vdx_flash_stamps_read(void* host, size_t bytes) {
     VDX_CHECK(host && bytes <= sizeof(g_fl_stamps), "flash_stamps_read: bad buffer");
     const hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fl_stamps), bytes, 0, hipMemcpyDeviceToHost);

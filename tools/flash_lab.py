@@ -92,14 +92,15 @@ for lvl in (int(x) for x in args.levels.split(",")):
             same = "" if t == "base" or "base" not in outs else ("  bits==base" if torch.equal(outs[t], outs["base"]) else "  bits!=base")
             err = f"  max rel err {worst:.2e}{same}"
         print(f"  {t:14s} median {med:7.3f} ms  min {mn:7.3f}  {fl / med / 1e9:7.1f} TFLOP/s  x{med / base_med:5.3f} of base{err}", flush=True)
-    if "stamps" in libs:
+    for stag in [t for t in libs if t.startswith("stamps")]:
         import numpy as np
-        lib = libs["stamps"]
+        lib = libs[stag]
+        ppk = "pp" in stag
         lib.vdx_flash_stamps_read.restype = C.c_int
         lib.vdx_flash_stamps_read.argtypes = [C.c_void_p, C.c_size_t]
-        nb = min(n_seq * heads * ((hw + 255) // 256), 8192)
+        nb = min(n_seq * heads * ((hw + 511) // 512), 4096) * 2 if ppk else min(n_seq * heads * ((hw + 255) // 256), 8192)
         buf = np.zeros((nb * 4, 8), dtype=np.uint64)
-        run(lib, qkv, outs["stamps"], Cc, n_seq, hw, heads)
+        run(lib, qkv, outs[stag], Cc, n_seq, hw, heads)
         torch.cuda.synchronize()
         assert lib.vdx_flash_stamps_read(buf.ctypes.data, buf.nbytes) == 0
         b = buf.astype(np.float64)
@@ -107,9 +108,11 @@ for lvl in (int(x) for x in args.levels.split(",")):
         ok = tiles > 0
         per = b[ok, :4] / tiles[ok, None]
         print("  stamps (shader cycles per K/V tile and wave, median [p10 .. p90] over %d waves; %d tiles per wave):" % (ok.sum(), int(np.median(tiles[ok]))))
-        for i, nm in enumerate(("DMA issue", "S MFMAs + row max", "exp / cvt / sums + P.V MFMAs", "barrier (incl. vmcnt(0))")):
+        names = ("matrix segment (S + P.V MFMAs)", "barrier after it", "vector segment (DMA + softmax)", "barrier after it (incl. vmcnt(0))") if ppk else \
+            ("DMA issue", "S MFMAs + row max", "exp / cvt / sums + P.V MFMAs", "barrier (incl. vmcnt(0))")
+        for i, nm in enumerate(names):
             col = per[:, i]
-            print(f"    {nm:30s} {np.median(col):8.0f}  [{np.percentile(col, 10):7.0f} .. {np.percentile(col, 90):7.0f}]")
+            print(f"    {nm:36s} {np.median(col):8.0f}  [{np.percentile(col, 10):7.0f} .. {np.percentile(col, 90):7.0f}]")
         tot = b[ok, 4] / tiles[ok]
         print(f"    {'whole tile (loop only)':30s} {np.median(tot):8.0f}   = 1024 MFMA cycles -> {1024 / np.median(tot) * 100:.1f} % of one wave's share; x2 waves per SIMD")
     del outs, qkv
