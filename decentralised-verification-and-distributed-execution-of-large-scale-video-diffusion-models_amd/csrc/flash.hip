@@ -18,18 +18,17 @@
 //   * row sums by v_dot2_f32_f16 against ones, row maxima by v_max3_f32 — both as FOUR independent chains per
 //     sub-block: a dependent chain of either costs 8.3 cycles per instruction, independent ones 5.3
 //     (tools/micro/coissue.hip, profiles/r04_flash.md).
-// Two kernels share this arithmetic bit for bit:
-//   flash_attn_kernel<QB, CAUSAL, VROW>  256-thread blocks, two per CU: every shape (cross-attention, the CLIP tower,
-//                                        short sequences);
-//   flash_pp_kernel                      512-thread blocks, the two waves of a SIMD in alternating matrix / vector
-//                                        segments (round 4): long self-attention with V as rows — levels 0 and 1.
+// Blocks are 256 threads, two per CU: a SIMD holds one wave of each.  profiles/r04_flash.md has the accounting of a tile
+// (timing-only builds, phase stamps, instruction costs) and the measured reason why an explicit pairing of the two waves of
+// a SIMD in alternating matrix / vector segments (a 512-thread "ping-pong" kernel, built in round 4, bit-identical, commit
+// "flash: ping-pong kernel experiment") is not faster: beside a wave that streams MFMAs, the softmax's vector mix is all
+// but starved, whichever wave is older or has the priority.
 #include "attn_common.h"
 
 // Diagnostic switches (tools/flash_abl.sh builds them into csrc/build/abl/libflash_<tag>.so; the product defines none):
 //   FL_ABL_NOEXP / NOSUM / NOMAX / NODMA / NOKREAD / NOVREAD / NOBAR   timing-only builds with one part of the tile
 //       removed (WRONG RESULTS by construction) — profiles/r04_flash.md's ablation table;
-//   FL_STAMPS   per-wave s_memtime sums of the tile's phases into g_fl_stamps (read back with vdx_flash_stamps_read);
-//   FL_PP = 0 | 1   never / always the ping-pong kernel;  FL_PP_PRIO = 0 | 1 | 2   no s_setprio / vector wave / matrix wave.
+//   FL_STAMPS   per-wave s_memtime sums of the tile's phases into g_fl_stamps (read back with vdx_flash_stamps_read).
 #ifdef FL_STAMPS
 static __device__ unsigned long long g_fl_stamps[8 * 32768];     // [block * waves + wave][8]: four phase sums, total, tiles
 #define FL_T(i)                                                     \
@@ -57,13 +56,6 @@ struct FlashP {
 
 typedef const __attribute__((address_space(1))) void* fl_gptr_t;
 typedef __attribute__((address_space(3))) void* fl_lptr_t;
-
-// a wave-uniform pointer the compiler shall keep in SGPRs (folds away when it already is)
-__device__ __forceinline__ const char* fl_uniform(const char* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const char*)(((unsigned long long)hi << 32) | lo);
-}
 
 // exchange with lane ^ 32 without LDS: v_permlane32_swap of (x, x) leaves the low half's value in a, the high half's in b
 __device__ __forceinline__ float max_xor32(float x) {
@@ -447,338 +439,6 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     fl_store<QB>(p, st, o_acc, seq, head, q0, r32, h);
 }
 
-// ---- the ping-pong form (round 4): long self-attention, V as rows ------------------------------------------------------
-// What profiles/r04_flash.md found in the kernel above (level 0, 5.15 ms): its time is the SUM of its parts — timing-only
-// builds without exp -13 %, without row max -9 %, without row sums -4 %, without DMA -9 %, without K reads -7 %, the MFMAs
-// alone 63 % — because the vector port of a SIMD serves its two waves one instruction at a time (v_exp_f32 8.6 cycles,
-// everything else 4.9-5.3, a DEPENDENT max3 / dot2c chain 8.3; an MFMA takes the port for a few cycles of its 32), and
-// because a wave streaming MFMAs that is older (or has priority) lets its partner issue one vector instruction per MFMA:
-// two identical waves drift into the same phase and wait for the same pipe (tools/micro/coissue.hip).
-// Here the pairing is explicit.  A block is 512 threads; waves w and w + 4 share a SIMD; a workgroup barrier separates
-// PHASES in which one of them is in its MATRIX segment (S of tile i and P.V of tile i - 1: 32 MFMAs and their LDS fragment
-// reads in a fixed software pipeline, nothing else) while the other is in its VECTOR segment (softmax of its tile, and its
-// share of the LDS-DMA of a later tile).  Waves 4-7 run one phase behind waves 0-3.  All eight waves read the same K / V
-// tiles (512 queries per block: half the DMA instructions and LDS writes per query) through a ring of four 16 KB tiles:
-//   interval b = between workgroup barriers b and b + 1;  group X = waves 0-3, Y = waves 4-7
-//   X: matrix(i) in interval 1 + 2i, vector(i) in 2 + 2i;  Y: matrix(i) in 2 + 2i, vector(i) in 3 + 2i
-//   matrix(i) reads K(i), V(i - 1) and opens with the wave's LDS-DMA: X issues V(i + 2), Y issues K(i + 3)  (tiles 0, 1
-//   and K(2) come from the prologue): a slot is rewritten one interval after its last reader; the issuing wave waits for
-//   its DMA at the head of its NEXT matrix segment (a whole tile period in flight: the barriers carry no fence), whose
-//   closing barrier publishes the tile one interval before its first reader.
-// Arithmetic, operand layouts and the order of every sum are those of the kernel above: the bits are identical.
-// A plain workgroup barrier: no fence, so LDS-DMA a wave has in flight stays in flight across it (what it must have
-// finished is waited for with flpp_wait_vm in front).  The compiler may move nothing across it.
-#define FLPP_BAR()                                      \
-    do {                                                \
-        __builtin_amdgcn_sched_barrier(0);              \
-        asm volatile("s_barrier" ::: "memory");         \
-        __builtin_amdgcn_sched_barrier(0);              \
-    } while (0)
-template <int N>
-__device__ __forceinline__ void flpp_wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// LDS fragment reads of the matrix segment as inline asm with COUNTED waits.  Two reasons: hipcc puts s_waitcnt vmcnt(0) in
-// front of a ds_read_b64_tr_b16 that follows an LDS-DMA it cannot tell apart (the wave's DMA of a LATER tile would be waited
-// for in the middle of the matrix segment), and it sinks reads towards their use.  LDS operations complete in issue order
-// and the segment issues nothing else that counts in lgkmcnt, so "all but the N youngest" is exact; a wait takes the
-// fragment as an in/out operand so that the MFMAs that consume it cannot be scheduled in front of it.
-typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) const char* fl_lds_t;
-template <int OFF_BYTES>
-__device__ __forceinline__ void flpp_ds_read_b128(f16x8& d, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF_BYTES));
-}
-template <int OFF_BYTES>
-__device__ __forceinline__ void flpp_ds_read_tr(u32x2v& lo, u32x2v& hi, unsigned addr) {      // one V^T operand: 2 x 8 bytes
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                 : "=&v"(lo), "=&v"(hi)
-                 : "v"(addr), "n"(OFF_BYTES), "n"(OFF_BYTES + 512));
-}
-template <int N>
-__device__ __forceinline__ void flpp_wait_lgkm(f16x8& d) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void flpp_wait_lgkm(u32x2v& lo, u32x2v& hi) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N));
-}
-__device__ __forceinline__ f16x8 flpp_frag(const u32x2v& lo, const u32x2v& hi) {
-    struct { u32x2v lo, hi; } pr = {lo, hi};
-    return __builtin_bit_cast(f16x8, pr);
-}
-// LDS byte offset of this lane's K fragment 0 of keys 0-31 inside a tile: row krow, chunk h ^ swizzle; fragment ks is the
-// chunk (2 ks + h) ^ swizzle = this address ^ (ks << 5) (tile bases are multiples of 128); keys 32-63: + 4096
-__device__ __forceinline__ unsigned flpp_k_addr(int krow, int h) {
-    return (unsigned)(krow * 128 + ((h ^ ((krow >> 1) & 7)) << 4));
-}
-
-// K fragments of keys 0-31 of a tile: requested at the END of the vector segment in front of the matrix segment that uses
-// them (the tile has been visible for an interval by then), so that no LDS latency opens the matrix segment.  They are
-// the only LDS operations outstanding when that matrix segment starts.
-__device__ __forceinline__ void flpp_read_k0(unsigned tile_base, unsigned ka, f16x8 (&kf0)[4]) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) flpp_ds_read_b128<0>(kf0[ks], (tile_base + ka) ^ (ks << 5));
-}
-
-// One matrix segment, straight-line, in a fixed order; `n` = LDS reads outstanding, oldest first:
-//   entry: K0[0..3] (n = 4)            issue K1[0..3] (keys 32-63)                     n = 8
-//   4 x { wait K0[ks] ; 2 S MFMAs }                                                    n = 4       (+ 2 offset MFMAs when OFF)
-//   4 x { wait K1[ks] ; 2 S MFMAs ; issue V operand ks (2 reads) }                     n = 5 .. 8  (+ 2 offset MFMAs)
-//   4 x { wait V[f]   ; 2 P.V MFMAs ; issue V operand 4 + f }                          n = 8
-//   4 x { wait V[4+f] ; 2 P.V MFMAs }                                                  n = 6, 4, 2, 0
-// every fragment is requested at least four MFMAs (128 cycles) before its wait.
-template <bool DO_S, bool DO_PV>
-__device__ __forceinline__ void flpp_matrix(bool OFF, unsigned k_base, unsigned v_base, unsigned ka, unsigned tr0, unsigned tr1,
-                                            int h, const f16x8 (&qf)[2][4], const f16x8 (&pf)[2][4], f16x8 (&kf0)[4], const FlSoft<2>& st,
-                                            f32x16 (&s_acc)[2][2], f32x16 (&o_acc)[2][2]) {
-    f32x16 zero16;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) zero16[j] = 0.f;
-    f16x8 kf1[4];
-    u32x2v vlo[8], vhi[8];
-#define FLPP_SB() __builtin_amdgcn_sched_barrier(0)
-#define FLPP_MM_S(KB, KS, KF)                                                                                                          \
-    do {                                                                                                                               \
-        s_acc[0][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(KF, qf[0][KS], KS == 0 ? zero16 : s_acc[0][KB], 0, 0, 0);                 \
-        s_acc[1][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(KF, qf[1][KS], KS == 0 ? zero16 : s_acc[1][KB], 0, 0, 0);                 \
-    } while (0)
-#define FLPP_MM_OFF(KB)                                                                                                                \
-    do {                                                                                                                               \
-        f16x8 e0 = FlSoft<2>::e0(h);         /* built here (4 moves): four registers that need not live through the loop */            \
-        asm volatile("" : "+v"(e0));                                                                                                   \
-        s_acc[0][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, st.negm[0], s_acc[0][KB], 0, 0, 0);                                   \
-        s_acc[1][KB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, st.negm[1], s_acc[1][KB], 0, 0, 0);                                   \
-    } while (0)
-#define FLPP_MM_PV(F)                                                                                                                  \
-    do {                                                                                                                               \
-        const f16x8 vf_ = flpp_frag(vlo[F], vhi[F]);                                                                                   \
-        o_acc[0][(F) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_, pf[0][(F) >> 1], o_acc[0][(F) & 1], 0, 0, 0);                   \
-        o_acc[1][(F) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf_, pf[1][(F) >> 1], o_acc[1][(F) & 1], 0, 0, 0);                   \
-    } while (0)
-    // V operand f = 2 kk + db: bytes kk * 2048 of the V tile, transposed-read address tr0 (db 0) | tr1 (db 1)
-#define FLPP_RD_V(F) flpp_ds_read_tr<((F) >> 1) * 2048>(vlo[F], vhi[F], v_base + (((F) & 1) ? tr1 : tr0))
-    FLPP_SB();
-    if (DO_S) {
-        flpp_ds_read_b128<4096>(kf1[0], k_base + ka);
-        flpp_ds_read_b128<4096>(kf1[1], (k_base + ka) ^ 32);
-        flpp_ds_read_b128<4096>(kf1[2], (k_base + ka) ^ 64);
-        flpp_ds_read_b128<4096>(kf1[3], (k_base + ka) ^ 96);
-        FLPP_SB();
-        flpp_wait_lgkm<7>(kf0[0]); FLPP_MM_S(0, 0, kf0[0]); FLPP_SB();
-        flpp_wait_lgkm<6>(kf0[1]); FLPP_MM_S(0, 1, kf0[1]); FLPP_SB();
-        flpp_wait_lgkm<5>(kf0[2]); FLPP_MM_S(0, 2, kf0[2]); FLPP_SB();
-        flpp_wait_lgkm<4>(kf0[3]); FLPP_MM_S(0, 3, kf0[3]); FLPP_SB();
-        if (OFF) { FLPP_MM_OFF(0); }          // (wave-uniform branch)
-        FLPP_SB();
-        if (DO_PV) {
-            flpp_wait_lgkm<3>(kf1[0]); FLPP_MM_S(1, 0, kf1[0]); FLPP_SB(); FLPP_RD_V(0); FLPP_SB();      // outstanding: K1[1..3] V0      = 5
-            flpp_wait_lgkm<4>(kf1[1]); FLPP_MM_S(1, 1, kf1[1]); FLPP_SB(); FLPP_RD_V(1); FLPP_SB();      // K1[2..3] V0 V1               = 6
-            flpp_wait_lgkm<5>(kf1[2]); FLPP_MM_S(1, 2, kf1[2]); FLPP_SB(); FLPP_RD_V(2); FLPP_SB();      // K1[3] V0 V1 V2               = 7
-            flpp_wait_lgkm<6>(kf1[3]); FLPP_MM_S(1, 3, kf1[3]); FLPP_SB(); FLPP_RD_V(3); FLPP_SB();      // V0 .. V3                     = 8
-        } else {
-            flpp_wait_lgkm<3>(kf1[0]); FLPP_MM_S(1, 0, kf1[0]); FLPP_SB();
-            flpp_wait_lgkm<2>(kf1[1]); FLPP_MM_S(1, 1, kf1[1]); FLPP_SB();
-            flpp_wait_lgkm<1>(kf1[2]); FLPP_MM_S(1, 2, kf1[2]); FLPP_SB();
-            flpp_wait_lgkm<0>(kf1[3]); FLPP_MM_S(1, 3, kf1[3]); FLPP_SB();
-        }
-        if (OFF) { FLPP_MM_OFF(1); }
-        FLPP_SB();
-    } else {
-        FLPP_RD_V(0); FLPP_RD_V(1); FLPP_RD_V(2); FLPP_RD_V(3);
-        FLPP_SB();
-    }
-    if (DO_PV) {
-        flpp_wait_lgkm<6>(vlo[0], vhi[0]); FLPP_MM_PV(0); FLPP_SB(); FLPP_RD_V(4); FLPP_SB();
-        flpp_wait_lgkm<6>(vlo[1], vhi[1]); FLPP_MM_PV(1); FLPP_SB(); FLPP_RD_V(5); FLPP_SB();
-        flpp_wait_lgkm<6>(vlo[2], vhi[2]); FLPP_MM_PV(2); FLPP_SB(); FLPP_RD_V(6); FLPP_SB();
-        flpp_wait_lgkm<6>(vlo[3], vhi[3]); FLPP_MM_PV(3); FLPP_SB(); FLPP_RD_V(7); FLPP_SB();
-        flpp_wait_lgkm<6>(vlo[4], vhi[4]); FLPP_MM_PV(4); FLPP_SB();
-        flpp_wait_lgkm<4>(vlo[5], vhi[5]); FLPP_MM_PV(5); FLPP_SB();
-        flpp_wait_lgkm<2>(vlo[6], vhi[6]); FLPP_MM_PV(6); FLPP_SB();
-        flpp_wait_lgkm<0>(vlo[7], vhi[7]); FLPP_MM_PV(7); FLPP_SB();
-    }
-#undef FLPP_SB
-#undef FLPP_MM_S
-#undef FLPP_MM_OFF
-#undef FLPP_MM_PV
-#undef FLPP_RD_V
-}
-
-__global__ __launch_bounds__(512) void flash_pp_kernel(const FlashP p) {
-    constexpr int QB = 2;
-    __shared__ __attribute__((aligned(128))) char smem[4 * 16384];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
-    const int r32 = lane & 31, h = lane >> 5;
-    int pair, qblk;
-    fl_block_map(p, pair, qblk);
-    const int head = pair % p.heads, seq = pair / p.heads;
-    const int kvb = seq / p.seq_per_kv;
-    const int q0 = (qblk * 8 + wave) * 64;
-
-    f16x8 qf[QB][4];
-    fl_load_q<QB>(p, seq, head, q0, r32, h, qf);
-
-    // ---- staging: a K or V half tile (8 KB) = 2 instructions of a 4-wave group; lane l of wave gw fills LDS row
-    // i * 32 + gw * 8 + (l >> 3), 16-byte slot l & 7, swizzles as in the kernel above.  A source address is a wave-uniform
-    // base (SGPRs: tensor + head + tile, advanced per tile by scalar adds) + ONE 32-bit lane offset (row st_row0, swizzled
-    // chunk; the second piece is 32 rows further: the same swizzle, a uniform distance) — global_load_lds's saddr form.
-    const char* zp = (const char*)g_zero_page;
-    const int st_row0 = gtid >> 3, st_row1 = st_row0 + 32;
-    const int ch0 = (gtid & 7) ^ ((st_row0 >> 1) & 7);                 // (row + 32: the same swizzle)
-    const int chv = (gtid & 7) ^ (((st_row0 >> 1) & 1) << 2);
-    const char* kbase = (const char*)(p.k + (size_t)kvb * p.skv_pad * p.ldk + head * 64);
-    const char* vbase = (const char*)(p.vt + (size_t)kvb * p.skv_pad * p.ldvt + head * 64);
-    const unsigned koff = (unsigned)(st_row0 * p.ldk + ch0 * 8) * 2u, voff = (unsigned)(st_row0 * p.ldvt + chv * 8) * 2u;
-    const size_t kstep = (size_t)128 * p.ldk, vstep = (size_t)128 * p.ldvt;     // bytes per tile of 64 rows
-    const int ntiles = (p.skv + 63) >> 6;
-    // `base`: uniform address of the tile's first row; off: my lane offset; half: bytes of 32 rows
-    auto issue_half = [&](const char* base, unsigned off, size_t half, int t, int v_half) __attribute__((always_inline)) {
-        char* dst = smem + (t & 3) * 16384 + v_half * 8192 + gw * 1024;
-        const int k0 = t * 64;
-        if (k0 + 64 > p.skv_pad) {                                    // tile crosses skv_pad (wave-uniform, last tile only):
-            const char* s0 = k0 + st_row0 >= p.skv_pad ? zp : base + off;          // rows past it come from the zero page
-            const char* s1 = k0 + st_row1 >= p.skv_pad ? zp : base + half + off;
-            __builtin_amdgcn_global_load_lds((fl_gptr_t)s0, (fl_lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((fl_gptr_t)s1, (fl_lptr_t)(dst + 4096), 16, 0, 0);
-        } else {
-            const char *b0 = fl_uniform(base), *b1 = fl_uniform(base + half);   // SGPR pairs: the saddr form, one lane-offset VGPR
-            __builtin_amdgcn_global_load_lds((fl_gptr_t)(b0 + off), (fl_lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((fl_gptr_t)(b1 + off), (fl_lptr_t)(dst + 4096), 16, 0, 0);
-        }
-    };
-    // prologue: X stages K(0), V(0), V(1); Y stages K(1), K(2)
-    if (grp == 0) {
-        issue_half(kbase, koff, kstep / 2, 0, 0);
-        issue_half(vbase, voff, vstep / 2, 0, 1);
-        if (1 < ntiles) issue_half(vbase + vstep, voff, vstep / 2, 1, 1);
-    } else {
-        if (1 < ntiles) issue_half(kbase + kstep, koff, kstep / 2, 1, 0);
-        if (2 < ntiles) issue_half(kbase + 2 * kstep, koff, kstep / 2, 2, 0);
-    }
-    // my group's running source of the steady state: X streams V from tile 2, Y streams K from tile 3
-    const char* rbase = grp == 0 ? vbase + 2 * vstep : kbase + 3 * kstep;
-    const unsigned roff = grp == 0 ? voff : koff;
-    const size_t rstep = grp == 0 ? vstep : kstep;
-    const int rlead = grp == 0 ? 2 : 3;
-
-    f32x16 o_acc[QB][2], s_acc[QB][2];
-    f16x8 pf[QB][4];
-    FlSoft<QB> st;
-    st.init();
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o_acc[qb][0][j] = o_acc[qb][1][j] = 0.f;
-    const int krow = pi_row(r32);
-    const unsigned lds0 = (unsigned)(size_t)(fl_lds_t)smem;      // LDS byte address of the ring
-    const unsigned ka = flpp_k_addr(krow, h);
-    const unsigned tr0 = (unsigned)fl_tr_addr(lane), tr1 = tr0 ^ 64;
-
-    flpp_wait_vm<0>();
-    FLPP_BAR();                            // barrier 0: the prologue's tiles have landed
-    if (grp == 1) FLPP_BAR();              // Y sits out interval 0
-    f16x8 kf0[4];
-    flpp_read_k0(lds0, ka, kf0);
-#ifdef FL_STAMPS
-    unsigned long long fl_sum[4] = {0, 0, 0, 0}, fl_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long fl_first = fl_last;
-#endif
-    // vector segment of tile i: my share of the DMA, then softmax(i): s_acc -> pf, l_run
-    auto vector_segment = [&](int i) __attribute__((always_inline)) {
-#if !defined(FL_PP_PRIO) || FL_PP_PRIO == 1
-        // tools/micro/coissue.hip: a wave that streams MFMAs and is the older one (or has the priority) lets its SIMD
-        // partner issue ONE vector instruction per MFMA (32-40 cycles each); with the priority on the vector wave both
-        // run at their own rate (v_exp 10.4 instead of 8.6 cycles, an MFMA every 32.4)
-        __builtin_amdgcn_s_setprio(1);
-#endif
-        const int k0 = i * 64;
-        if (k0 + 64 > p.skv) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (k0 + kb * 32 + acc_key(j, h) >= p.skv) s_acc[qb][kb][j] = NEG_BIG;
-        }
-        st.tile(s_acc, o_acc, pf, h);
-        if (i + 1 < ntiles) flpp_read_k0(lds0 + ((i + 1) & 3) * 16384, ka, kf0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // my share of the LDS-DMA, at the head of a MATRIX segment (an LDS-DMA instruction holds its wave for 100-170 cycles —
-    // profiles/r04_flash.md — which the matrix segment can afford and the vector segment, the longer one, cannot): first
-    // wait for what I issued one tile period ago — the barrier that ends this segment then publishes it
-    auto dma_segment = [&](int i) __attribute__((always_inline)) {
-        flpp_wait_vm<0>();
-#ifndef FL_ABL_NODMA
-        if (i + rlead < ntiles) issue_half(rbase, roff, rstep / 2, i + rlead, grp ^ 1);
-#endif
-        rbase += rstep;
-    };
-    // ---- tile 0: S only
-    dma_segment(0);
-    flpp_matrix<true, false>(false, lds0, lds0, ka, tr0, tr1, h, qf, pf, kf0, st, s_acc, o_acc);
-    FLPP_BAR();
-    vector_segment(0);
-    FLPP_BAR();
-    for (int i = 1; i < ntiles; ++i) {
-        // ================= matrix segment: S(i) = K(i).Q^T - m, O^T += V(i-1)^T.P(i-1)^T =================
-        const unsigned Ks = lds0 + (i & 3) * 16384, Vs = lds0 + ((i - 1) & 3) * 16384 + 8192;
-#ifdef FL_PP_SOLO      // (diagnostic: waves 4-7 only keep the barriers company — the segments' lengths without a SIMD partner)
-        if (grp == 0)
-#endif
-        {
-        dma_segment(i);
-        flpp_matrix<true, true>(st.offset_on, Ks, Vs, ka, tr0, tr1, h, qf, pf, kf0, st, s_acc, o_acc);
-        }
-        FL_T(0);
-        FLPP_BAR();
-        FL_T(1);
-#ifdef FL_PP_SOLO
-        if (grp == 0)
-#endif
-        vector_segment(i);
-        FL_T(2);
-        FLPP_BAR();
-#if defined(FL_PP_PRIO) && FL_PP_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);       // (diagnostic: the priority on the MATRIX wave instead)
-#endif
-        FL_T(3);
-    }
-    // ---- P.V of the last tile
-    flpp_wait_vm<0>();
-    flpp_matrix<false, true>(false, lds0, lds0 + ((ntiles - 1) & 3) * 16384 + 8192, ka, tr0, tr1, h, qf, pf, kf0, st, s_acc, o_acc);
-    FLPP_BAR();
-    FLPP_BAR();
-#ifdef FL_STAMPS
-    {
-        const unsigned long long tot = __builtin_amdgcn_s_memtime() - fl_first;
-        if (lane == 0 && blockIdx.x < 4096) {
-            unsigned long long* dst = g_fl_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
-            dst[0] = fl_sum[0]; dst[1] = fl_sum[1]; dst[2] = fl_sum[2]; dst[3] = fl_sum[3];
-            dst[4] = tot; dst[5] = (unsigned long long)ntiles - 1;
-        }
-    }
-#endif
-    if (grp == 0) FLPP_BAR();              // X sits out the last interval (Y's matrix(ntiles))
-    fl_store<QB>(p, st, o_acc, seq, head, q0, r32, h);
-}
-
-// The ping-pong kernel's tiles are 512 queries: taken when the last block of a sequence is at least 3/4 full (9216, 2304
-// tokens) and there are enough K/V tiles to amortise its prologue.  FL_PP = 0 | 1 (diagnostic builds) overrides.
-static bool flash_pp_wanted(int sq, int skv) {
-#if defined(FL_PP)
-    return FL_PP != 0 && skv >= 256;
-#else
-    const int last = sq % 512;
-    return sq >= 2048 && skv >= 1024 && (last == 0 || last >= 256);
-#endif
-}
-
 template <bool VROW>
 static int flash_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                         void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
@@ -801,13 +461,6 @@ static int flash_launch(const void* q, int ldq, const void* k, int ldk, const vo
     p.heads = heads;
     p.npairs = n_seq * heads;
     p.xcd = p.npairs % 8 == 0 ? 1 : 0;
-    // the ping-pong form (512 queries per block): long self-attention with V as rows, when padding sq to 512 wastes little
-    if (VROW && !causal && flash_pp_wanted(sq, skv)) {
-        p.nqb = (sq + 511) / 512;
-        VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
-        hipLaunchKernelGGL(flash_pp_kernel, dim3(p.nqb * p.npairs), dim3(512), 0, (hipStream_t)stream, p);
-        return vdx_launch_status("vdx_flash_attn_rows_f16");
-    }
     p.nqb = two ? (sq + 255) / 256 : (sq + 127) / 128;
     VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
     if (two) {

@@ -26,9 +26,6 @@ if [ "$1" == "--all" ]; then
     one novalu "-DFL_ABL_NOEXP -DFL_ABL_NOSUM -DFL_ABL_NOMAX" &
     one mfmaonly "-DFL_ABL_NOEXP -DFL_ABL_NOSUM -DFL_ABL_NOMAX -DFL_ABL_NODMA -DFL_ABL_NOBAR -DFL_ABL_NOKREAD -DFL_ABL_NOVREAD" &
     wait
-    one nos "-DFL_ABL_NOS" &
-    one nopv "-DFL_ABL_NOPV" &
-    wait
 else
     one "$1" "$2"
 fi
