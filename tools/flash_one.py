@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Dev tool: run the L0 spatial self-attention shape a few times (for rocprofv3 --pmc)."""
+"""Dev tool: run the L0 spatial self-attention shape a few times, V as rows of one q|k|v matrix (what the UNet runs), for
+rocprofv3 --pmc passes (tools/flash_pmc.sh)."""
 import os
 import sys
 
@@ -12,10 +13,9 @@ from vdx import ops  # noqa: E402
 dev = torch.device("cuda:0")
 hw, C, n_seq = 9216, 320, 48
 M = n_seq * hw
-qk = torch.randn(M, 2 * C, device=dev, dtype=torch.float16)
-vt = torch.randn(C, M, device=dev, dtype=torch.float16)
+qkv = torch.randn(M, 3 * C, device=dev, dtype=torch.float16)
 out = torch.empty(M, C, device=dev, dtype=torch.float16)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    ops.flash_attn(qk[:, :C], qk[:, C:], vt, n_seq=n_seq, sq=hw, skv=hw, skv_pad=hw, heads=5, seq_per_kv=1,
-                   scale=0.125, out=out)
+    ops.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_seq=n_seq, sq=hw, skv=hw, skv_pad=hw, heads=5, seq_per_kv=1,
+                   scale=0.125, out=out, v_rows=True)
 torch.cuda.synchronize()
