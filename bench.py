@@ -99,6 +99,27 @@ def cpu_baseline(frames: int, threads: int):
                       f"({dt:.1f} s), scaled x{24 / frames:g} to the 24-frame step"}
 
 
+def copy_activity_of_a_step(step, i, lats):
+    """One more step under torch.profiler: do the parameter pulls of the peer transport show up as blit KERNELS
+    (`__amd_rocclr_copyBuffer`: compute units) or only as memcpy activities (copy engines)?  vdx/shard.py claims the
+    latter for remote pulls; on one GPU (local copies) the runtime uses blit kernels.  Answered here, not assumed."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            step(i, lats)
+            torch.cuda.synchronize()
+        blit = memcpy = 0
+        for ev in prof.events():
+            nm = ev.name or ""
+            if "copyBuffer" in nm or "rocclr_copy" in nm:
+                blit += 1
+            elif nm.startswith("Memcpy") or "hipMemcpyAsync" == nm:
+                memcpy += 1
+        return {"step_blit_copy_kernels": blit, "step_memcpy_activities": memcpy}
+    except Exception as e:      # noqa: BLE001 — a diagnostic: never fail the bench line for it
+        return {"step_copy_activity_error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +214,8 @@ def main():
             from vdx.comm import Comm
             comm = Comm.from_torch(dev)
         unet.shard_(rank, world, comm=comm)       # 1/N of every unit per GPU, gathered per unit on a side stream
+        if args.rehearse_dist and args.as_world > 1 and world == 1:
+            unet.W.rehearse_copies = args.as_world      # a gather = as_world copies: the host-side call count of a node
     if args.ff_block_mb:
         unet.ff_block_bytes = args.ff_block_mb << 20
     if args.no_lean:
@@ -250,12 +273,15 @@ def main():
     # the roofline object needs the dominant kernel's launch durations from inside the timed region; the two kernels that
     # can be it (30.5 / 30.8 ms per forward; the next family has 22) get events, the other ~500 launches per step do not
     ops.PROFILE_ONLY = None if args.profile_all else ("gemm_kernel<256, 320, 4, 2, 1, false, true, 0>", "flash_attn_kernel<2, false")
+    store = unet.W if hasattr(unet.W, "transport") else None
+    g0, h0 = (store.gathers, store.gather_host_s) if store is not None else (0, 0.0)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         lats = step(args.warmup + i, lats)
     fence()
     dt = time.perf_counter() - t0
+    g1, h1 = (store.gathers, store.gather_host_s) if store is not None else (0, 0.0)
     ops.PROFILE = None
     finite = all(bool(torch.isfinite(lat.float()).all()) for lat in lats)
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
@@ -296,8 +322,16 @@ def main():
             "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
             "output_finite": finite,
         }
-        if hasattr(unet.W, "transport"):
-            out["shard_transport"] = "rccl-c-abi" if unet.W.comm is not None else unet.W.transport
+        if store is not None:
+            # how the parameter gathers travelled, whether the peer mapping reproduced the collective (world > 1 only), and
+            # what they cost the HOST: gathers per step, copies per gather, host time spent enqueueing them per step
+            out["shard_transport"] = "rccl-c-abi" if store.comm is not None else store.transport
+            out["shard_peer_self_check"] = store.peer_self_check
+            out["shard_gathers_per_step"] = round((g1 - g0) / args.steps, 1)
+            out["shard_copies_per_gather"] = (store.rehearse_copies or store.world) if store.transport == "peer" else None
+            out["shard_gather_host_ms_per_step"] = round(1e3 * (h1 - h0) / args.steps, 3)
+            if args.profile_all:
+                out.update(copy_activity_of_a_step(step, args.warmup + args.steps, lats))
         if args.rehearsal or args.rehearse_dist:
             out["rehearsal"] = True      # not the driver's measurement: one-GPU rehearsal of the distributed path / dev flags
         if plan_world != world and args.rehearse_dist and my_frames != 24:

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 import warnings
 from typing import Callable, Dict, List, Optional
 
@@ -126,6 +127,8 @@ class ShardedStore:
         self.gathers = 0
         self.transport = "collective"
         self.peer_self_check = "not run"       # "passed" | "failed" once a world > 1 store has compared peer vs collective
+        self.rehearse_copies = 0               # > 1 (world of 1 only): issue a gather as that many copies (see _peer_gather)
+        self.gather_host_s = 0.0               # host time spent ENQUEUEING gathers (perf_counter around the transport call)
         self._peer_ptrs = None
         self._opened: List = []                # (peer pid, handle) of every mapping this store holds a reference to
         want = transport or os.environ.get("VDX_SHARD_TRANSPORT") or ("peer" if self._cuda else "collective")
@@ -221,9 +224,17 @@ class ShardedStore:
         from . import _lib
         es = out.element_size()
         n = self._padded[unit] // self.world
-        srcs = (C.c_void_p * self.world)(*[p + self._arena_off[unit] * es for p in self._peer_ptrs])
-        _lib.check(_lib.load().vdx_peer_gather(out.data_ptr(), srcs, self.world, n * es, self._side.cuda_stream),
-                   "vdx_peer_gather")
+        k = self.rehearse_copies
+        if k > 1 and self.world == 1 and (n * es) % (16 * k) == 0:
+            # one-GPU rehearsal of a bigger world (bench.py --as-world): the same bytes as `k` copies, so that the host
+            # issues what it would issue on a node (one ctypes call, k hipMemcpyAsync per unit)
+            base = self._peer_ptrs[0] + self._arena_off[unit] * es
+            srcs = (C.c_void_p * k)(*[base + i * (n * es // k) for i in range(k)])
+            rc = _lib.load().vdx_peer_gather(out.data_ptr(), srcs, k, n * es // k, self._side.cuda_stream)
+        else:
+            srcs = (C.c_void_p * self.world)(*[p + self._arena_off[unit] * es for p in self._peer_ptrs])
+            rc = _lib.load().vdx_peer_gather(out.data_ptr(), srcs, self.world, n * es, self._side.cuda_stream)
+        _lib.check(rc, "vdx_peer_gather")
 
     # ---- mapping protocol -------------------------------------------------------------------
     def __contains__(self, name):
@@ -265,6 +276,7 @@ class ShardedStore:
             else:
                 dist.all_gather(list(out.chunk(self.world)), shard, group=self.group)
 
+        t0 = time.perf_counter()
         if self._cuda:
             with torch.cuda.stream(self._side):
                 if self._released[slot] is not None:
@@ -275,6 +287,7 @@ class ShardedStore:
             self._ready[slot] = ev
         else:
             run()
+        self.gather_host_s += time.perf_counter() - t0
         self._resident[slot] = unit
         self.gathers += 1
 

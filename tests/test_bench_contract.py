@@ -60,3 +60,21 @@ def test_bench_selects_the_baseline_configuration_of_the_world_size():
     assert plan(24, 2, 0, 4, no_chunking=True).ranges == ((0, 24), (0, 24))
     assert plan(48, 4, 0, 4).ranges == ((0, 16), (12, 28), (24, 40), (36, 48))
     assert plan(96, 8, 0, 4).ranges[-2:] == ((72, 88), (84, 96)) and len(plan(96, 8, 0, 4).ranges) == 8
+
+
+def test_perf_guard_flags_a_slower_dominant_kernel(tmp_path):
+    """tools/perf_guard.py: a guarded kernel whose average launch is > 4 % slower than the committed profile fails the run."""
+    import subprocess
+    import sys
+    hdr = '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+    row = '"void {}(X)",{},1,{},1.0,1,1,0\n'
+    ref, new_ok, new_bad = tmp_path / "ref.csv", tmp_path / "ok.csv", tmp_path / "bad.csv"
+    k1, k2 = "gemm_kernel<256, 320, 4, 2, 1, false, true, 0>", "flash_attn_kernel<2, false, true>"
+    ref.write_text(hdr + row.format(k1, 105, 900000.0) + row.format(k2, 45, 2098000.0))
+    new_ok.write_text(hdr + row.format(k1, 105, 925000.0) + row.format(k2, 45, 2050000.0))
+    new_bad.write_text(hdr + row.format(k1, 105, 995000.0) + row.format(k2, 45, 2050000.0))
+    tool = os.path.join(ROOT, "tools", "perf_guard.py")
+    ok = subprocess.run([sys.executable, tool, str(new_ok), str(ref)], capture_output=True, text=True)
+    bad = subprocess.run([sys.executable, tool, str(new_bad), str(ref)], capture_output=True, text=True)
+    assert ok.returncode == 0 and "perf_guard: ok" in ok.stdout, ok.stdout
+    assert bad.returncode == 1 and "FAIL" in bad.stdout and "+10.6 %" in bad.stdout, bad.stdout

@@ -8,6 +8,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-profile > $OUT/stats.log 2>&1
 cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv
+# per-launch time of the dominant kernels against the previous round's committed profile (fails loudly on > 4 %)
+PREV=$(ls profiles/r0*_kernel_stats.csv | sort | tail -1)
+python3 tools/perf_guard.py $OUT/kernel_stats.csv $PREV | tee $OUT/perf_guard.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/fetch -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write -- $B > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma -- $B > $OUT/pmc_mfma.log 2>&1
