@@ -289,6 +289,20 @@ extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void
                   partition_samples, false, p, stream);
 }
 
+// statistics only: the per-(sample, channel) scale / shift pairs ([n_samples][C][2] fp32) are left in the workspace at
+// *scale_shift_offset bytes — what a consumer that applies the normalisation itself reads (vdx_tconv_gn_f16)
+extern "C" int vdx_groupnorm_stats_f16(const void* x, int C, int ldx, const void* gamma, const void* beta, float eps, int G,
+                                       int n_samples, int rows_per_sample, void* workspace, int partition_samples,
+                                       size_t* scale_shift_offset, vdx_stream_t stream) {
+    VDX_CHECK(scale_shift_offset, "groupnorm_stats: null pointer");
+    GnP p;
+    if (const int rc = gn_run(x, C, ldx, nullptr, 0, 0, gamma, beta, eps, G, n_samples, rows_per_sample, 0, nullptr, 0, workspace,
+                              partition_samples, true, p, stream))
+        return rc;
+    *scale_shift_offset = (size_t)((const char*)p.ab - (const char*)workspace);
+    return 0;
+}
+
 // ---- GroupNorm folded into the Linear that follows it (Transformer2DModel / TransformerTemporalModel: norm -> proj_in,
 // no activation between them).  With the per-(sample, channel) scale a and shift b of the statistics,
 //     W . (a x + b) + bias  =  (W diag(a_s)) . x  +  (bias + W . b_s):

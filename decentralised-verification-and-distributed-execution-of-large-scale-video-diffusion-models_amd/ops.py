@@ -350,6 +350,55 @@ def groupnorm(x, gamma, beta, *, groups, n_samples, rows_per_sample, eps, silu_a
     return out
 
 
+def tconv_gn_supported(C: int, N: int, F: int) -> bool:
+    """Shapes `tconv_gn` (K3, csrc/tconv_fused.hip) takes: C % 64 == 0, N % 320 == 0, F % 8 == 0."""
+    return bool(_lib.load().vdx_tconv_gn_supported(C, N, F))
+
+
+def tconv_gn_preferred(C: int, N: int, B: int, F: int, S: int) -> bool:
+    """K3 supported AND expected to be faster than the apply pass + TCONV3 GEMM (level 0 of the XL UNet)."""
+    return bool(_lib.load().vdx_tconv_gn_preferred(C, N, B, F, S))
+
+
+def tconv_gn(x, gamma, beta, w, *, bias=None, residual=None, groups, B, F, S, eps, partition_samples=0, out=None):
+    """Conv3d (3,1,1) of SiLU(GroupNorm5d(x)) — one link of TemporalConvLayer's chain — without the normalised tensor:
+    the statistics pass (`vdx_groupnorm_stats_f16`, n_samples = B, rows_per_sample = F*S) leaves a scale / shift pair per
+    (sample, channel); K3 (`vdx_tconv_gn_f16`) applies them, and the SiLU, to its staged image in LDS.  x: raw rows
+    [B*F*S][C]; w: packed temporal weights [N][3*C] (packing.pack_tconv)."""
+    lib = _lib.load()
+    r, Cc, ldx = _rows(x, "x")
+    M = B * F * S
+    N, K = w.shape
+    if r < M or K != 3 * Cc or gamma.numel() != Cc or beta.numel() != Cc or not w.is_contiguous():
+        raise VdxError(f"tconv_gn: x [{r}][{Cc}], w [{N}][{K}], gamma {gamma.numel()}, M = {M}: shapes do not match")
+    if not tconv_gn_supported(Cc, N, F):
+        raise VdxError(f"tconv_gn: C={Cc}, N={N}, F={F} not supported")
+    if bias is not None and bias.numel() != N:
+        raise VdxError(f"tconv_gn: bias has {bias.numel()} elements, N={N}")
+    ldr = 0
+    if residual is not None:
+        rr, rc, ldr = _rows(residual, "residual")
+        if rr < M or rc < N:
+            raise VdxError(f"tconv_gn: residual {tuple(residual.shape)} smaller than [{M}][{N}]")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < N:
+        raise VdxError("tconv_gn: out too small")
+    need = lib.vdx_groupnorm_workspace_part(B, F * S, Cc, groups, partition_samples)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    off = C.c_size_t(0)
+    _lib.check(lib.vdx_groupnorm_stats_f16(_p(x, "x"), Cc, ldx, _p(gamma, "gamma"), _p(beta, "beta"), float(eps), groups, B, F * S,
+                                           ws.data_ptr(), partition_samples, C.byref(off), _stream()), "vdx_groupnorm_stats_f16")
+    _lib.check(lib.vdx_tconv_gn_f16(_p(x, "x"), ldx, ws.data_ptr() + off.value, _p(w, "w"), _p(bias, "bias"), _p(residual, "residual"),
+                                    ldr, _p(out, "out"), ldo, B, F, S, Cc, N, _stream()), "vdx_tconv_gn_f16")
+    return out
+
+
 def layernorm(x, gamma, beta, *, M, eps=1e-5, out=None):
     lib = _lib.load()
     r, Cc, ldx = _rows(x, "x")

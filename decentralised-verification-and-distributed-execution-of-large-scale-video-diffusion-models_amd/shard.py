@@ -72,12 +72,18 @@ def _ipc_release(lib, pid, handle):
 
 class ShardedStore:
     def __init__(self, tensors: Dict[str, torch.Tensor], unit_of: Callable[[str], Optional[str]],
-                 schedule: List[str], rank: int, world: int, group=None, comm=None, transport: Optional[str] = None):
+                 schedule: List[str], rank: int, world: int, group=None, comm=None, transport: Optional[str] = None,
+                 merge_bytes: int = 64 << 20):
         """`unit_of(name)` -> unit id, or None for tensors kept replicated (small stem tensors).
         `comm`: a `vdx.comm.Comm` — the gathers then go through the C-ABI (`vdx_allgather_shard`, RCCL) instead of
         `torch.distributed`.  `transport`: "peer" | "collective" (module docstring); default from VDX_SHARD_TRANSPORT,
-        else "peer" on GPUs."""
+        else "peer" on GPUs.  `merge_bytes`: neighbours of the schedule are gathered TOGETHER while their sum stays within
+        this many bytes (fewer, larger transfers: the level-0 / level-1 units of the XL UNet are 2-18 MB each and a gather
+        is `world` copies or one collective whatever its size); the two gather buffers are sized by the largest unit
+        anyway (95 MB), so merging below that costs no memory.  0 = one gather per unit."""
         self.rank, self.world, self.group, self.comm = rank, world, group, comm
+        if merge_bytes > 0:
+            schedule, unit_of = _merge_units(tensors, unit_of, list(schedule), merge_bytes)
         self.schedule = list(schedule)
         self._pos = {u: i for i, u in enumerate(self.schedule)}
         self.replicated: Dict[str, torch.Tensor] = {}
@@ -317,6 +323,33 @@ class ShardedStore:
         nxt = self.schedule[(self._pos[unit] + 1) % len(self.schedule)]
         if nxt != unit and nxt not in self._resident:
             self._gather_into(slot ^ 1, nxt)
+
+
+def _merge_units(tensors, unit_of, schedule, merge_bytes):
+    """Greedy merge of consecutive schedule units into gather groups of at most `merge_bytes` (a unit larger than that
+    stays alone).  Returns the group schedule and the tensor-name -> group function."""
+    es = next(iter(tensors.values())).element_size()
+    size = {u: 0 for u in schedule}
+    for name, t in tensors.items():
+        u = unit_of(name)
+        if u is not None:
+            if u not in size:
+                raise KeyError(f"tensor {name!r} maps to unit {u!r} which is not in the schedule")
+            size[u] += _round_up(t.numel(), ALIGN) * es
+    # (never coarser than 1/24 of the model: a small model keeps a schedule worth prefetching through)
+    merge_bytes = min(merge_bytes, sum(size.values()) // 24)
+    group_of, groups, cur, cur_bytes = {}, [], None, 0
+    for u in schedule:
+        if cur is None or cur_bytes + size[u] > merge_bytes:
+            cur, cur_bytes = u, 0                      # a group is named after its first unit
+            groups.append(cur)
+        group_of[u] = cur
+        cur_bytes += size[u]
+
+    def unit_of_group(name):
+        u = unit_of(name)
+        return None if u is None else group_of[u]
+    return groups, unit_of_group
 
 
 def _numel(shape):

@@ -78,6 +78,7 @@ class UNet3DConditionModel(nn.Module):
         self.lean_attn = True          # (with ff_block_bytes set) spatial self-attention over image halves
         self.fold_norm_proj_in = True  # GroupNorm -> proj_in as per-sample weights where the Linear is weights-stationary
         self.fuse_ff = True            # K8 where the width allows (False: LayerNorm, GEGLU GEMM, GEMM + residual)
+        self.fuse_tconv = True         # K3 where it is faster — level 0 (False: GroupNorm apply pass + temporal-conv GEMM; "always": wherever the shape allows, tests)
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
         self._text_ref = None                  # (encoder_hidden_states object, its version, (B, device), padded copy)
@@ -287,14 +288,14 @@ class UNet3DConditionModel(nn.Module):
             return ".".join(parts[:3])
         return None                              # conv_in/out, time embedding, conv_norm_out
 
-    def shard_(self, rank: int, world: int, group=None, comm=None, transport=None):
+    def shard_(self, rank: int, world: int, group=None, comm=None, transport=None, merge_bytes: int = 64 << 20):
         """Keep 1/world of every unit on this GPU; gather per unit with prefetch (vdx/shard.py).  `comm`: gather through
         the C-ABI RCCL entry point instead of torch.distributed (vdx/comm.py); `transport`: "peer" (mapped shard arenas,
         copy-engine pulls: the default on GPUs) or "collective"."""
         from .shard import ShardedStore
         if not isinstance(self.W, dict):
             raise VdxError("weights are already sharded")
-        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group, comm, transport)
+        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group, comm, transport, merge_bytes)
         self.ff_block_bytes = 128 << 20
         if self._device.type == "cuda":
             torch.cuda.empty_cache()
@@ -366,6 +367,14 @@ class UNet3DConditionModel(nn.Module):
         M = B * F * S
         y = x
         for i in (1, 2, 3, 4):
+            wi = W[f"{p}.conv{i}.weight"]
+            if self.fuse_tconv and (ops.tconv_gn_supported(y.shape[1], wi.shape[0], F) if self.fuse_tconv == "always"
+                                    else ops.tconv_gn_preferred(y.shape[1], wi.shape[0], B, F, S)):
+                # K3: the GroupNorm apply + SiLU happen inside the convolution (statistics pass + one kernel; the
+                # normalised tensor is never written)
+                y = ops.tconv_gn(y, W[f"{p}.conv{i}.0.weight"], W[f"{p}.conv{i}.0.bias"], wi, bias=W[f"{p}.conv{i}.bias"],
+                                 residual=x if i == 4 else None, groups=g, B=B, F=F, S=S, eps=1e-5)
+                continue
             n = ops.groupnorm(y, W[f"{p}.conv{i}.0.weight"], W[f"{p}.conv{i}.0.bias"], groups=g, n_samples=B,
                               rows_per_sample=F * S, eps=1e-5, silu_act=True)
             y = ops.gemm(n, W[f"{p}.conv{i}.weight"], M=M, mode=ops.TCONV3, bias=W[f"{p}.conv{i}.bias"],

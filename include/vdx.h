@@ -143,6 +143,25 @@ int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c
                            const void* gamma, const void* beta, float eps, int G,
                            int n_samples, int rows_per_sample, int silu,
                            void* y, int ldy, void* workspace, int partition_samples, vdx_stream_t stream);
+/* The statistics pass alone: leaves scale[s][c] = rstd_s,g * gamma_c and shift[s][c] = beta_c - mean_s,g * scale as
+ * [n_samples][C][2] fp32 at byte *scale_shift_offset of `workspace` (vdx_groupnorm_workspace_part bytes), for a consumer that
+ * applies the normalisation itself (vdx_tconv_gn_f16).                                                               */
+int vdx_groupnorm_stats_f16(const void* x, int C, int ldx, const void* gamma, const void* beta, float eps, int G,
+                            int n_samples, int rows_per_sample, void* workspace, int partition_samples,
+                            size_t* scale_shift_offset, vdx_stream_t stream);
+/* K3 — TemporalConvLayer's Sequential(GroupNorm, SiLU, Conv3d (3,1,1)) with the normalisation applied INSIDE the convolution
+ * (SURVEY.md §2.3 row TemporalConvLayer, App. A.4; reached four times per layer from fsdp_chunked_coherent.py:140):
+ *   out[(b*F + f)*S + p][n] = bias[n] + residual + sum_kt sum_c w[n][(c/64)*192 + kt*64 + c%64] * silu(x[(b*F + f+kt-1)*S + p][c] * scale[b][c] + shift[b][c])
+ * with zero rows for frames outside [0, F) (the padding applies to the normalised tensor).  x: raw rows [B*F*S][ldx];
+ * scale_shift: [B][C][2] fp32 from vdx_groupnorm_stats_f16 (n_samples = B, rows_per_sample = F*S); w: the packed temporal
+ * weights of vdx_gemm_f16's VDX_GEMM_TCONV3 mode ([N][3*C]).  Supported: C % 64 == 0, N % 320 == 0, F % 8 == 0
+ * (vdx_tconv_gn_supported); other shapes take vdx_groupnorm_f16 + vdx_gemm_f16.                                        */
+int vdx_tconv_gn_supported(int C, int N, int F);
+/* 1 when K3 is expected to beat vdx_groupnorm_f16 + vdx_gemm_f16 on this shape (one column tile, the chip filled twice over) */
+int vdx_tconv_gn_preferred(int C, int N, int B, int F, int S);
+int vdx_tconv_gn_f16(const void* x, int ldx, const float* scale_shift, const void* w, const void* bias,
+                     const void* residual, int ldr, void* out, int ldo, int B, int F, int S, int C, int N,
+                     vdx_stream_t stream);
 /* In-place softmax over the first `cols` columns of each of `rows` rows of x (row stride ld), logits scaled by
  * `scale` in fp32: the probabilities of AutoencoderKL's mid-block attention (one 512-channel head over h*w
  * tokens; diffusers Attention with upcast softmax), reached from fsdp_chunked_coherent.py:223.            */

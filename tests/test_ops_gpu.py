@@ -406,6 +406,71 @@ def test_tconv3(gpu, B, Fr, HW, C, Co):
     close(out, ref + res)
 
 
+def _tconv_gn_ref(x5, gamma, beta, w, b, res, eps=1e-5):
+    """fp32 statement of one link of TemporalConvLayer's chain: GroupNorm(32) over (C/32, F, h, w) jointly,
+    SiLU, Conv3d (3,1,1) with zero padding in time — every op output rounded to fp16 as the reference's fp16 modules do."""
+    n = h(F.group_norm(x5, 32, gamma, beta, eps))
+    a = h(F.silu(n))
+    y = F.conv3d(a, w, b, padding=(1, 0, 0))
+    B, Co, Fr, S, _ = y.shape
+    y = y[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * S, Co)
+    return y + res if res is not None else y
+
+
+@pytest.mark.parametrize("B,Fr,S,C,Co,resid", [
+    (2, 24, 16, 64, 320, True),        # FT = 12: two frame chunks with halo frames, level-0 like
+    (1, 16, 40, 128, 320, False),      # FT = 16: the whole clip in one tile; 40 pixels = 2.5 pixel blocks (tail rows)
+    (2, 12, 9, 64, 640, True),         # FT = 12, fewer pixels than one block, two column tiles
+    (1, 8, 33, 192, 320, True),        # FT = 8, three channel slices
+    (2, 48, 16, 64, 320, False),       # FT = 16: three chunks
+])
+def test_tconv_gn_fused(gpu, B, Fr, S, C, Co, resid):
+    """K3 (csrc/tconv_fused.hip): statistics pass + the temporal convolution that normalises its staged image in LDS,
+    against the fp32 reference AND against the un-fused kernels (GroupNorm apply pass + TCONV3 GEMM)."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + Fr * 10 + C)
+    x5 = h(torch.randn(B, C, Fr, S, 1, generator=g) * 1.5 + 0.3 * torch.randn(1, C, 1, 1, 1, generator=g))
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.3 * torch.randn(C, generator=g))
+    w = h(torch.randn(Co, C, 3, 1, 1, generator=g) / math.sqrt(3 * C))
+    b = h(torch.randn(Co, generator=g) * 0.1)
+    M = B * Fr * S
+    res = h(torch.randn(M, Co, generator=g)) if resid else None
+    ref = _tconv_gn_ref(x5, gamma, beta, w, b, res)
+    rows = x5[..., 0].permute(0, 2, 3, 1).reshape(M, C).contiguous().half().to(gpu)
+    dv = lambda t: None if t is None else t.half().to(gpu)   # noqa: E731
+    wp = packing.pack_tconv3(w).half().to(gpu)
+    assert ops.tconv_gn_supported(C, Co, Fr)
+    out = ops.tconv_gn(rows, dv(gamma), dv(beta), wp, bias=dv(b), residual=dv(res), groups=32, B=B, F=Fr, S=S, eps=1e-5)
+    close(out, ref, tol=4e-3)
+    n = ops.groupnorm(rows, dv(gamma), dv(beta), groups=32, n_samples=B, rows_per_sample=Fr * S, eps=1e-5, silu_act=True)
+    unfused = ops.gemm(n, wp, M=M, mode=ops.TCONV3, bias=dv(b), residual=dv(res), tconv=(Fr, S))
+    close(out, unfused.float().cpu(), tol=2e-3)
+    assert torch.equal(out, ops.tconv_gn(rows, dv(gamma), dv(beta), wp, bias=dv(b), residual=dv(res), groups=32, B=B, F=Fr, S=S, eps=1e-5))
+
+
+def test_tconv_gn_fused_large_mean_and_batch_invariance(gpu):
+    """K3 with channels whose mean is far from 0 (the statistics pass is the cancellation-free one) and a sample's bits
+    whatever batch it is computed in (partition_samples pins the statistics' slab partition)."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(77)
+    B, Fr, S, C, Co = 2, 16, 48, 64, 320
+    x5 = h(torch.randn(B, C, Fr, S, 1, generator=g) * 0.7 + 40.0 * torch.randn(1, C, 1, 1, 1, generator=g))
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.3 * torch.randn(C, generator=g))
+    w = h(torch.randn(Co, C, 3, 1, 1, generator=g) / math.sqrt(3 * C))
+    M = B * Fr * S
+    ref = _tconv_gn_ref(x5, gamma, beta, w, None, None)
+    rows = x5[..., 0].permute(0, 2, 3, 1).reshape(M, C).contiguous().half().to(gpu)
+    dv = lambda t: t.half().to(gpu)   # noqa: E731
+    wp = packing.pack_tconv3(w).half().to(gpu)
+    both = ops.tconv_gn(rows, dv(gamma), dv(beta), wp, groups=32, B=B, F=Fr, S=S, eps=1e-5, partition_samples=B)
+    close(both, ref, tol=6e-3)
+    one = ops.tconv_gn(rows[M // 2:], dv(gamma), dv(beta), wp, groups=32, B=1, F=Fr, S=S, eps=1e-5, partition_samples=B)
+    assert torch.equal(one, both[M // 2:])
+    assert not ops.tconv_gn_supported(C, Co, 1) and not ops.tconv_gn_supported(C, Co, 20) and not ops.tconv_gn_supported(C, 256, 16)
+    with pytest.raises(Exception, match="not supported"):
+        ops.tconv_gn(rows[:S], dv(gamma), dv(beta), wp, groups=32, B=1, F=1, S=S, eps=1e-5)
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ns,rps,c1,c2,G,silu", [
     (6, 35, 64, 0, 32, True), (3, 300, 320, 0, 32, True), (2, 130, 64, 128, 32, True),
