@@ -78,3 +78,8 @@ def test_perf_guard_flags_a_slower_dominant_kernel(tmp_path):
     bad = subprocess.run([sys.executable, tool, str(new_bad), str(ref)], capture_output=True, text=True)
     assert ok.returncode == 0 and "perf_guard: ok" in ok.stdout, ok.stdout
     assert bad.returncode == 1 and "FAIL" in bad.stdout and "+10.6 %" in bad.stdout, bad.stdout
+    # a box that is 5 % slower as a whole is not a regression of any kernel
+    slow = tmp_path / "slow.csv"
+    slow.write_text(hdr + row.format(k1, 105, 945000.0) + row.format(k2, 45, 2203000.0))
+    r = subprocess.run([sys.executable, tool, str(slow), str(ref)], capture_output=True, text=True)
+    assert r.returncode == 0 and "box factor" in r.stdout, r.stdout

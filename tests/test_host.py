@@ -227,6 +227,51 @@ def test_gemm_plan_is_host_only_and_splits_the_mostly_idle_last_round():
         assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) != 0 and b"rows [" in lib.vdx_last_error(), bad
 
 
+def test_split_k_is_not_taken_by_any_product_of_the_xl_forward():
+    """whether a product runs its tail as split-K (a different summation order) depends on its row count, so a
+    sample's bits could depend on the window length.  Pinned here: for every GEMM the XL UNet calls with allow_ksplit
+    (3x3 convolutions, temporal convolutions, feed-forward output projections) at 24-, 16- and 12-frame windows,
+    vdx_gemm_plan_ksplit answers "no" — the planner's 42 MB workspace limit and its cost model keep split-K out of the
+    UNet; a change of its threshold that lets one in fails here before it moves a golden."""
+    import ctypes as C
+    from vdx import _lib
+    lib = _lib.load()
+    widths, B = (320, 640, 1280, 1280), 2
+
+    def ks(M, N, K, mode, taps, hh=0, ww=0, F_=0, hw=0):
+        g = _lib.GemmArgs()
+        g.a = g.w = g.out = 1 << 20
+        g.M, g.N, g.K, g.mode, g.c1 = M, N, K, mode, K // taps
+        g.lda, g.ldo = K // taps, N
+        if mode == 1:
+            g.h_in = g.h_out = hh
+            g.w_in = g.w_out = ww
+            g.stride = 1
+        if mode == 2:
+            g.frames, g.hw = F_, hw
+        s_, k_, w_ = C.c_int32(-1), C.c_int32(-1), C.c_size_t(1)
+        assert lib.vdx_gemm_plan_ksplit(C.byref(g), C.byref(s_), C.byref(k_), C.byref(w_)) == 0, lib.vdx_last_error()
+        return k_.value
+    n = 0
+    for F_ in (24, 16, 12):
+        for lvl, Cw in enumerate(widths):
+            hh, ww = 72 >> lvl, 128 >> lvl
+            S = hh * ww
+            M = B * F_ * S
+            cins = {Cw}
+            if lvl < 3:
+                cins |= {Cw + widths[lvl + 1], 2 * Cw, Cw + (widths[lvl - 1] if lvl else Cw)}    # up-block concats, previous level in
+            if lvl:
+                cins.add(widths[lvl - 1])
+            for cin in sorted(cins):
+                assert ks(M, Cw, 9 * cin, 1, 9, hh, ww) == 0, (F_, lvl, cin)          # resnet conv1 / conv2
+                n += 1
+            assert ks(M, Cw, 3 * Cw, 2, 3, F_=F_, hw=S) == 0, (F_, lvl)               # temporal convolution
+            assert ks(M, Cw, 4 * Cw, 0, 1) == 0, (F_, lvl)                            # feed-forward output projection
+            n += 2
+    assert n >= 60
+
+
 def test_split_k_plan_never_takes_the_upsample_to_size_gather():
     """the split-K kernels are the VAR = 1 instantiation whose gather shifts by `upsample` (0 | 1); with
     upsample = 2 (nearest-to-size) they would read the wrong source pixels, in bounds and silently.  vdx_gemm_plan_ksplit

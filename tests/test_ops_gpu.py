@@ -1130,6 +1130,59 @@ def test_groupnorm_folded_into_linear_large_mean(gpu):
     close(out, ref, tol=6e-3)
 
 
+def _wide_affine(C, g):
+    """gamma spanning 1e-3 .. 30 (log-uniform, both signs), beta up to +-5: the large-gamma analogue of the *_large_mean
+    cases (real norm3 / norm1 channels have |gamma| far above 1 or near 0; folding gamma into fp16 weights
+    rounds W * gamma once where the reference rounds the normalised activation first)."""
+    mag = torch.exp(torch.empty(C).uniform_(math.log(1e-3), math.log(30.0), generator=g))
+    sign = torch.where(torch.rand(C, generator=g) < 0.25, -1.0, 1.0)
+    return h(mag * sign), h(torch.empty(C).uniform_(-5.0, 5.0, generator=g))
+
+
+def test_fused_kernels_with_wide_gamma_and_beta(gpu):
+    """K7 (second design), K8 and the GroupNorm fold with the norm's affine folded into fp16 weights, gamma in 1e-3 .. 30 and
+    beta in +-5, against the fp32 statements.  The tolerance is relative to the output's scale (parity with a TRAINED
+    checkpoint stays unpinned: the reference holds no fixture)."""
+    ops, _ = _ops()
+    from vdx import packing
+    g = torch.Generator().manual_seed(123)
+    inner, heads, B, Fr, HW = 320, 5, 1, 24, 40
+    M = B * Fr * HW
+    gamma, beta = _wide_affine(inner, g)
+    t = h(torch.randn(M, inner, generator=g) * 1.5 + 0.3)
+    # K7b: the weights are scaled so that the scores stay in a trained network's range (|gamma| up to 30 enters q AND k)
+    wq, wk, wv, wo = (h(torch.randn(inner, inner, generator=g) * s_) for s_ in (0.006, 0.006, 0.01, 0.05))
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    ref = _temporal_block_ref(t, gamma, beta, wq, wk, wv, wo, bo, B, Fr, HW, heads)
+    blob = packing.pack_k7b(wq, wk, wv, wo, gamma, beta, bo, 0.125).to(gpu)
+    out = ops.temporal_attn_block2(t.half().to(gpu), blob, B=B, F=Fr, HW=HW)
+    close(out, ref, tol=6e-3)
+    # K8
+    w1, b1 = h(torch.randn(8 * inner, inner, generator=g) * 0.01), h(torch.randn(8 * inner, generator=g) * 0.1)
+    w2, b2 = h(torch.randn(inner, 4 * inner, generator=g) * 0.03), h(torch.randn(inner, generator=g) * 0.1)
+    ref = _ff_ref(t, gamma, beta, w1, b1, w2, b2)
+    blob = packing.pack_k8(w1.to(gpu), b1.to(gpu), w2.to(gpu), b2.to(gpu), gamma.to(gpu), beta.to(gpu))
+    out = ops.ff_block(t.half().to(gpu), blob, M=M)
+    close(out, ref, tol=6e-3)
+    # GroupNorm -> proj_in fold
+    C, N, n_samples, rps = 320, 320, 3, 320
+    x = h(torch.randn(n_samples, rps, C, generator=g) * 1.3 + torch.randn(n_samples, 1, C, generator=g))
+    w, b = h(torch.randn(N, C, generator=g) * 0.02), h(torch.randn(N, generator=g) * 0.1)
+    ref = F.linear(F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1), w, b).reshape(n_samples * rps, N)
+    out = ops.groupnorm_linear(x.reshape(-1, C).half().to(gpu), gamma.half().to(gpu), beta.half().to(gpu), w.half().to(gpu),
+                               b.half().to(gpu), groups=32, n_samples=n_samples, rows_per_sample=rps, eps=1e-6)
+    close(out, ref, tol=6e-3)
+    # K3 applies the affine in fp32 (no fold): the same affine through it
+    S, Co = 32, 320
+    x5 = h(torch.randn(1, C, 16, S, 1, generator=g) * 1.5)
+    wt = h(torch.randn(Co, C, 3, 1, 1, generator=g) / math.sqrt(3 * C) / 8)
+    ref = _tconv_gn_ref(x5, gamma, beta, wt, None, None)
+    rows = x5[..., 0].permute(0, 2, 3, 1).reshape(16 * S, C).contiguous().half().to(gpu)
+    out = ops.tconv_gn(rows, gamma.half().to(gpu), beta.half().to(gpu), packing.pack_tconv3(wt).half().to(gpu), groups=32, B=1,
+                       F=16, S=S, eps=1e-5)
+    close(out, ref, tol=6e-3)
+
+
 def test_ff_block_strided_rows(gpu):
     """t and out as column blocks of wider matrices (leading dimensions larger than the width): same bits as contiguous rows."""
     ops, _ = _ops()
