@@ -151,6 +151,8 @@ def main():
                          "nats above the mean, as trained checkpoints have) — the lazy softmax offset of the flash kernel then "
                          "has to move; the default synthetic weights give near-uniform attention, its best case")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--rehearse-copies", action="store_true",
+                    help="with --rehearse-dist --as-world N on one GPU: issue every parameter gather as N copies (the host call count of a node)")
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP events around EVERY matrix kernel (the per-family table `gemm_kernels`): costs ~2.6 ms per step; the "
                          "default times only the two candidates for the dominant kernel (3x3-conv GEMM, spatial flash attention)")
@@ -214,8 +216,10 @@ def main():
             from vdx.comm import Comm
             comm = Comm.from_torch(dev)
         unet.shard_(rank, world, comm=comm)       # 1/N of every unit per GPU, gathered per unit on a side stream
-        if args.rehearse_dist and args.as_world > 1 and world == 1:
-            unet.W.rehearse_copies = args.as_world      # a gather = as_world copies: the host-side call count of a node
+        if args.rehearse_dist and args.rehearse_copies and args.as_world > 1 and world == 1:
+            # a gather = as_world LOCAL copies: the host-side call count of a node.  (On one GPU every one of them is a
+            # blit kernel on the GPU that is computing; on a node 7 of 8 are remote pulls.  An upper bound of the cost.)
+            unet.W.rehearse_copies = args.as_world
     if args.ff_block_mb:
         unet.ff_block_bytes = args.ff_block_mb << 20
     if args.no_lean:
