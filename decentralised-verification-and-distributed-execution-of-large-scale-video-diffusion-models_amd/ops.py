@@ -394,8 +394,16 @@ def tconv_gn(x, gamma, beta, w, *, bias=None, residual=None, groups, B, F, S, ep
     off = C.c_size_t(0)
     _lib.check(lib.vdx_groupnorm_stats_f16(_p(x, "x"), Cc, ldx, _p(gamma, "gamma"), _p(beta, "beta"), float(eps), groups, B, F * S,
                                            ws.data_ptr(), partition_samples, C.byref(off), _stream()), "vdx_groupnorm_stats_f16")
+    name = f"tconv_gn_kernel<{16 if F % 16 == 0 else 12 if F % 12 == 0 else 8}>"
+    timed = PROFILE is not None and _profiled(name)       # bench.py --profile-all: HIP events around this launch
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(lib.vdx_tconv_gn_f16(_p(x, "x"), ldx, ws.data_ptr() + off.value, _p(w, "w"), _p(bias, "bias"), _p(residual, "residual"),
                                     ldr, _p(out, "out"), ldo, B, F, S, Cc, N, _stream()), "vdx_tconv_gn_f16")
+    if timed:
+        ev1.record()
+        PROFILE.append((name, 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
 
