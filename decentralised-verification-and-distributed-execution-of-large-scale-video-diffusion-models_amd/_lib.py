@@ -48,7 +48,10 @@ SIGNATURES = {
     "vdx_groupnorm_workspace_part": (_sz, [_i, _i, _i, _i, _i]),
     "vdx_groupnorm_part_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "vdx_groupnorm_fold_linear_f16": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
-    "vdx_groupnorm_stats_f16": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _i, C.POINTER(_sz), _vp]),
+    "vdx_groupnorm_stats_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _i, C.POINTER(_sz), _vp]),
+    "vdx_conv3x3_gn_supported": (_i, [_i, _i, _i]),
+    "vdx_conv3x3_gn_preferred": (_i, [_i, _i, _i, _i, _i, _i]),
+    "vdx_conv3x3_gn_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "vdx_tconv_gn_supported": (_i, [_i, _i, _i]),
     "vdx_tconv_gn_preferred": (_i, [_i, _i, _i, _i, _i]),
     "vdx_tconv_gn_f16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),

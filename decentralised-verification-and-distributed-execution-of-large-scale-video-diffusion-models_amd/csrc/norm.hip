@@ -291,12 +291,12 @@ extern "C" int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void
 
 // statistics only: the per-(sample, channel) scale / shift pairs ([n_samples][C][2] fp32) are left in the workspace at
 // *scale_shift_offset bytes — what a consumer that applies the normalisation itself reads (vdx_tconv_gn_f16)
-extern "C" int vdx_groupnorm_stats_f16(const void* x, int C, int ldx, const void* gamma, const void* beta, float eps, int G,
-                                       int n_samples, int rows_per_sample, void* workspace, int partition_samples,
-                                       size_t* scale_shift_offset, vdx_stream_t stream) {
+extern "C" int vdx_groupnorm_stats_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2, const void* gamma,
+                                       const void* beta, float eps, int G, int n_samples, int rows_per_sample, void* workspace,
+                                       int partition_samples, size_t* scale_shift_offset, vdx_stream_t stream) {
     VDX_CHECK(scale_shift_offset, "groupnorm_stats: null pointer");
     GnP p;
-    if (const int rc = gn_run(x, C, ldx, nullptr, 0, 0, gamma, beta, eps, G, n_samples, rows_per_sample, 0, nullptr, 0, workspace,
+    if (const int rc = gn_run(x, c1, ldx, x2, c2, ldx2, gamma, beta, eps, G, n_samples, rows_per_sample, 0, nullptr, 0, workspace,
                               partition_samples, true, p, stream))
         return rc;
     *scale_shift_offset = (size_t)((const char*)p.ab - (const char*)workspace);

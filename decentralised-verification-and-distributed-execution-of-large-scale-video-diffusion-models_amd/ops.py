@@ -350,6 +350,77 @@ def groupnorm(x, gamma, beta, *, groups, n_samples, rows_per_sample, eps, silu_a
     return out
 
 
+def conv3x3_gn_preferred(c1: int, c2: int, N: int, n_img: int, h: int, w: int) -> bool:
+    """K1 supported AND expected to be faster than the apply pass + conv GEMM (level 0 of the XL UNet)."""
+    return bool(_lib.load().vdx_conv3x3_gn_preferred(c1, c2, N, n_img, h, w))
+
+
+def conv3x3_gn_supported(c1: int, c2: int, N: int) -> bool:
+    return bool(_lib.load().vdx_conv3x3_gn_supported(c1, c2, N))
+
+
+def conv3x3_gn(x, gamma, beta, w, *, x2=None, bias=None, bias2=None, rows_per_bias2=0, residual=None, groups, n_img, h, wd, eps,
+               partition_samples=0, out=None):
+    """Conv2d 3x3 (pad 1, stride 1) of SiLU(GroupNorm4d(cat(x, x2))) — conv1 / conv2 of ResnetBlock2D — without the
+    normalised tensor: the statistics pass (`vdx_groupnorm_stats_f16`, one sample per image) leaves a scale / shift pair per
+    (image, channel); K1 (`vdx_conv3x3_gn_f16`, csrc/conv_fused.hip) applies them, and the SiLU, to its staged image patch
+    in LDS.  x (and x2: the skip tensor of the up blocks): raw rows [n_img*h*wd][c]; w: packed weights [N][9*(c1+c2)]."""
+    lib = _lib.load()
+    r, c1, ldx = _rows(x, "x")
+    S = h * wd
+    M = n_img * S
+    c2 = ldx2 = 0
+    if x2 is not None:
+        r2, c2, ldx2 = _rows(x2, "x2")
+        if r2 < M:
+            raise VdxError(f"conv3x3_gn: x2 has {r2} rows, need {M}")
+    Cc = c1 + c2
+    N, K = w.shape
+    if r < M or K != 9 * Cc or gamma.numel() != Cc or beta.numel() != Cc or not w.is_contiguous():
+        raise VdxError(f"conv3x3_gn: x [{r}][{c1}] (+{c2}), w [{N}][{K}], gamma {gamma.numel()}, M = {M}: shapes do not match")
+    if not conv3x3_gn_supported(c1, c2, N):
+        raise VdxError(f"conv3x3_gn: c1={c1}, c2={c2}, N={N} not supported")
+    if bias is not None and bias.numel() != N:
+        raise VdxError(f"conv3x3_gn: bias has {bias.numel()} elements, N={N}")
+    ldb2 = 0
+    if bias2 is not None:
+        b2r, b2c, ldb2 = _rows(bias2, "bias2")
+        if rows_per_bias2 <= 0 or b2r * rows_per_bias2 < M or b2c < N:
+            raise VdxError("conv3x3_gn: bias2 does not cover M rows / N columns")
+    ldr = 0
+    if residual is not None:
+        rr, rc, ldr = _rows(residual, "residual")
+        if rr < M or rc < N:
+            raise VdxError(f"conv3x3_gn: residual {tuple(residual.shape)} smaller than [{M}][{N}]")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < N:
+        raise VdxError("conv3x3_gn: out too small")
+    need = lib.vdx_groupnorm_workspace_part(n_img, S, Cc, groups, partition_samples)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    off = C.c_size_t(0)
+    _lib.check(lib.vdx_groupnorm_stats_f16(_p(x, "x"), c1, ldx, _p(x2, "x2"), c2, ldx2, _p(gamma, "gamma"), _p(beta, "beta"), float(eps),
+                                           groups, n_img, S, ws.data_ptr(), partition_samples, C.byref(off), _stream()),
+               "vdx_groupnorm_stats_f16")
+    name = "conv3x3_gn_kernel"
+    timed = PROFILE is not None and _profiled(name)       # bench.py --profile-all: HIP events around this launch
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(lib.vdx_conv3x3_gn_f16(_p(x, "x"), ldx, _p(x2, "x2"), ldx2, c1, c2, ws.data_ptr() + off.value, _p(w, "w"), _p(bias, "bias"),
+                                      _p(bias2, "bias2"), rows_per_bias2, ldb2, _p(residual, "residual"), ldr, _p(out, "out"), ldo,
+                                      n_img, h, wd, N, _stream()), "vdx_conv3x3_gn_f16")
+    if timed:
+        ev1.record()
+        PROFILE.append((name, 2.0 * M * N * K, ev0, ev1, (M, N, K)))
+    return out
+
+
 def tconv_gn_supported(C: int, N: int, F: int) -> bool:
     """Shapes `tconv_gn` (K3, csrc/tconv_fused.hip) takes: C % 64 == 0, N % 320 == 0, F % 8 == 0."""
     return bool(_lib.load().vdx_tconv_gn_supported(C, N, F))
@@ -392,8 +463,8 @@ def tconv_gn(x, gamma, beta, w, *, bias=None, residual=None, groups, B, F, S, ep
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
         _gn_ws[key] = ws
     off = C.c_size_t(0)
-    _lib.check(lib.vdx_groupnorm_stats_f16(_p(x, "x"), Cc, ldx, _p(gamma, "gamma"), _p(beta, "beta"), float(eps), groups, B, F * S,
-                                           ws.data_ptr(), partition_samples, C.byref(off), _stream()), "vdx_groupnorm_stats_f16")
+    _lib.check(lib.vdx_groupnorm_stats_f16(_p(x, "x"), Cc, ldx, None, 0, 0, _p(gamma, "gamma"), _p(beta, "beta"), float(eps), groups, B,
+                                           F * S, ws.data_ptr(), partition_samples, C.byref(off), _stream()), "vdx_groupnorm_stats_f16")
     name = f"tconv_gn_kernel<{16 if F % 16 == 0 else 12 if F % 12 == 0 else 8}>"
     timed = PROFILE is not None and _profiled(name)       # bench.py --profile-all: HIP events around this launch
     if timed:

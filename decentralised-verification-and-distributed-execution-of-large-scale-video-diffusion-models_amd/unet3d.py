@@ -78,6 +78,7 @@ class UNet3DConditionModel(nn.Module):
         self.lean_attn = True          # (with ff_block_bytes set) spatial self-attention over image halves
         self.fold_norm_proj_in = True  # GroupNorm -> proj_in as per-sample weights where the Linear is weights-stationary
         self.fuse_ff = True            # K8 where the width allows (False: LayerNorm, GEGLU GEMM, GEMM + residual)
+        self.fuse_conv_gn = True       # K1 where it is faster — level 0 (False: GroupNorm apply pass + 3x3-conv GEMM; "always": wherever the shape allows, tests)
         self.fuse_tconv = True         # K3 where it is faster — level 0 (False: GroupNorm apply pass + temporal-conv GEMM; "always": wherever the shape allows, tests)
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
@@ -325,6 +326,18 @@ class UNet3DConditionModel(nn.Module):
         geo = (n_img, hh, ww, hh, ww, 1, False)
         B = n_img // F
         concat_in = x2 is not None
+        c1_, c2_ = x.shape[1], (x2.shape[1] if x2 is not None else 0)
+        k1 = (lambda cin1, cin2: self.fuse_conv_gn and (ops.conv3x3_gn_supported(cin1, cin2, cout) if self.fuse_conv_gn == "always"
+                                                        else ops.conv3x3_gn_preferred(cin1, cin2, cout, n_img, hh, ww)))
+        if k1(c1_, c2_):
+            # K1: GroupNorm apply + SiLU inside the convolution (statistics pass + one kernel): the normalised tensor — for
+            # the up blocks the [rows][C1 + C2] concat, the widest tensor of the block — is never written, so the memory-lean
+            # pieces below have nothing to do either
+            h = ops.conv3x3_gn(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], W[p + ".conv1.weight"], x2=x2, bias=W[p + ".conv1.bias"],
+                               bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, groups=g, n_img=n_img, h=hh, wd=ww, eps=eps)
+            del x, x2
+            return ops.conv3x3_gn(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], W[p + ".conv2.weight"], bias=W[p + ".conv2.bias"],
+                                  residual=sc, groups=g, n_img=n_img, h=hh, wd=ww, eps=eps)
         pieces = 0
         if self.ff_block_bytes and self.lean_concat and x2 is not None and M * cout * 2 > (64 << 20):
             # memory-lean mode, concat input (up path): the normalised concat [rows][C1 + C2] is the widest tensor of

@@ -146,9 +146,9 @@ int vdx_groupnorm_part_f16(const void* x, int c1, int ldx, const void* x2, int c
 /* The statistics pass alone: leaves scale[s][c] = rstd_s,g * gamma_c and shift[s][c] = beta_c - mean_s,g * scale as
  * [n_samples][C][2] fp32 at byte *scale_shift_offset of `workspace` (vdx_groupnorm_workspace_part bytes), for a consumer that
  * applies the normalisation itself (vdx_tconv_gn_f16).                                                               */
-int vdx_groupnorm_stats_f16(const void* x, int C, int ldx, const void* gamma, const void* beta, float eps, int G,
-                            int n_samples, int rows_per_sample, void* workspace, int partition_samples,
-                            size_t* scale_shift_offset, vdx_stream_t stream);
+int vdx_groupnorm_stats_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2, const void* gamma,
+                            const void* beta, float eps, int G, int n_samples, int rows_per_sample, void* workspace,
+                            int partition_samples, size_t* scale_shift_offset, vdx_stream_t stream);
 /* K3 — TemporalConvLayer's Sequential(GroupNorm, SiLU, Conv3d (3,1,1)) with the normalisation applied INSIDE the convolution
  * (SURVEY.md §2.3 row TemporalConvLayer, App. A.4; reached four times per layer from fsdp_chunked_coherent.py:140):
  *   out[(b*F + f)*S + p][n] = bias[n] + residual + sum_kt sum_c w[n][(c/64)*192 + kt*64 + c%64] * silu(x[(b*F + f+kt-1)*S + p][c] * scale[b][c] + shift[b][c])
@@ -156,6 +156,21 @@ int vdx_groupnorm_stats_f16(const void* x, int C, int ldx, const void* gamma, co
  * scale_shift: [B][C][2] fp32 from vdx_groupnorm_stats_f16 (n_samples = B, rows_per_sample = F*S); w: the packed temporal
  * weights of vdx_gemm_f16's VDX_GEMM_TCONV3 mode ([N][3*C]).  Supported: C % 64 == 0, N % 320 == 0, F % 8 == 0
  * (vdx_tconv_gn_supported); other shapes take vdx_groupnorm_f16 + vdx_gemm_f16.                                        */
+/* K1 — ResnetBlock2D's conv(SiLU(GroupNorm(x))) with the normalisation applied INSIDE the 3x3 convolution (SURVEY.md §2.3 row
+ * ResnetBlock2D, App. A.3; conv1 and conv2 of every ResNet block, reached from fsdp_chunked_coherent.py:140):
+ *   out[n*h*w + y*w + x][o] = bias[o] + bias2[(n*h*w) / rows_per_bias2][o] + residual + sum_{ky,kx,c} w[o][(c/64)*576 + (ky*3+kx)*64 + c%64]
+ *                             * silu(cat(a, a2)[n*h*w + (y+ky-1)*w + (x+kx-1)][c] * scale[n][c] + shift[n][c])
+ * with zero for pixels outside the image (the padding applies to the normalised tensor).  a / a2: raw rows (a2 / c2 = the skip
+ * tensor of the up blocks, or NULL / 0); scale_shift: [n_img][c1 + c2][2] fp32 from vdx_groupnorm_stats_f16 (n_samples = n_img,
+ * rows_per_sample = h*w); w: the packed weights of vdx_gemm_f16's VDX_GEMM_CONV3X3 mode.  Stride 1, no upsampling.
+ * Supported: c1 % 64 == 0, c2 % 64 == 0, N % 320 == 0; vdx_conv3x3_gn_preferred: expected to beat vdx_groupnorm_f16 + vdx_gemm_f16
+ * (one column tile, image width a multiple of 32, the chip filled twice over: level 0 of the XL UNet).                */
+int vdx_conv3x3_gn_supported(int c1, int c2, int N);
+int vdx_conv3x3_gn_preferred(int c1, int c2, int N, int n_img, int h, int w);
+int vdx_conv3x3_gn_f16(const void* a, int lda, const void* a2, int lda2, int c1, int c2, const float* scale_shift,
+                       const void* w, const void* bias, const void* bias2, int rows_per_bias2, int ldb2,
+                       const void* residual, int ldr, void* out, int ldo, int n_img, int h, int w_px, int N,
+                       vdx_stream_t stream);
 int vdx_tconv_gn_supported(int C, int N, int F);
 /* 1 when K3 is expected to beat vdx_groupnorm_f16 + vdx_gemm_f16 on this shape (one column tile, the chip filled twice over) */
 int vdx_tconv_gn_preferred(int C, int N, int B, int F, int S);

@@ -406,6 +406,60 @@ def test_tconv3(gpu, B, Fr, HW, C, Co):
     close(out, ref + res)
 
 
+@pytest.mark.parametrize("n,hh,ww,c1,c2,cout,temb,resid", [
+    (3, 12, 32, 64, 0, 320, True, False),       # two patch rows, one patch column; conv1 form (time-embedding row)
+    (2, 7, 64, 128, 0, 320, False, True),       # ragged patch rows (7 = 6 + 1), two patch columns; conv2 form (residual)
+    (2, 6, 40, 64, 64, 320, True, False),       # two sources (skip concat), ragged width (40 = 32 + 8)
+    (1, 18, 32, 192, 128, 640, True, True),     # five channel slices across the two sources, two column tiles
+    (4, 5, 9, 64, 0, 320, False, False),        # an image smaller than one patch
+])
+def test_conv3x3_gn_fused(gpu, n, hh, ww, c1, c2, cout, temb, resid):
+    """K1 (csrc/conv_fused.hip): statistics pass + the 3x3 convolution that normalises its staged image patch in LDS, against
+    the fp32 statement of ResnetBlock2D's conv(SiLU(GroupNorm(cat(x, skip)))) + time-embedding row + residual (every op
+    output rounded to fp16 as the reference's fp16 modules do) AND against the un-fused kernels."""
+    ops, packing = _ops()
+    g = torch.Generator().manual_seed(n * 100 + hh + ww + c1 + c2)
+    C_ = c1 + c2
+    x = h(torch.randn(n, C_, hh, ww, generator=g) * 1.5 + 0.4 * torch.randn(1, C_, 1, 1, generator=g))
+    gamma, beta = h(1 + 0.2 * torch.randn(C_, generator=g)), h(0.3 * torch.randn(C_, generator=g))
+    w = h(torch.randn(cout, C_, 3, 3, generator=g) / math.sqrt(9 * C_))
+    b = h(torch.randn(cout, generator=g) * 0.1)
+    frames = 2 if n % 2 == 0 else 1                    # images per time-embedding row
+    te = h(torch.randn(n // frames, cout, generator=g) * 0.3) if temb else None
+    M = n * hh * ww
+    res = h(torch.randn(M, cout, generator=g)) if resid else None
+    act = h(F.silu(h(F.group_norm(x, 32, gamma, beta, 1e-5))))
+    ref4 = F.conv2d(act, w, b, padding=1)
+    if temb:
+        ref4 = ref4 + te.repeat_interleave(frames, 0)[:, :, None, None]
+    ref = packing.nchw_to_rows(ref4)
+    if resid:
+        ref = ref + res
+    dv = lambda t: None if t is None else t.half().to(gpu)   # noqa: E731
+    rows = packing.nchw_to_rows(x).half().to(gpu)
+    xa = rows[:, :c1].contiguous()
+    xb = rows[:, c1:].contiguous() if c2 else None
+    wp = packing.pack_conv3x3(w.half()).to(gpu)
+    assert ops.conv3x3_gn_supported(c1, c2, cout)
+    kw = dict(x2=xb, bias=dv(b), bias2=dv(te), rows_per_bias2=frames * hh * ww, residual=dv(res), groups=32, n_img=n, h=hh, wd=ww, eps=1e-5)
+    out = ops.conv3x3_gn(xa, dv(gamma), dv(beta), wp, **kw)
+    close(out, ref, tol=4e-3)
+    nrm = ops.groupnorm(xa, dv(gamma), dv(beta), groups=32, n_samples=n, rows_per_sample=hh * ww, eps=1e-5, silu_act=True, x2=xb)
+    unf = ops.gemm(nrm, wp, M=M, mode=ops.CONV3X3, bias=dv(b), bias2=dv(te), rows_per_bias2=frames * hh * ww, residual=dv(res),
+                   conv=(n, hh, ww, hh, ww, 1, False))
+    close(out, unf.float().cpu(), tol=2e-3)
+    assert torch.equal(out, ops.conv3x3_gn(xa, dv(gamma), dv(beta), wp, **kw))
+    # a sample's bits do not depend on the batch it is computed in (tiles never span images; statistics per image)
+    if n > 1 and not temb:
+        S = hh * ww
+        one = ops.conv3x3_gn(xa[S:2 * S], dv(gamma), dv(beta), wp, x2=None if xb is None else xb[S:2 * S], bias=dv(b),
+                             residual=None if res is None else dv(res)[S:2 * S], groups=32, n_img=1, h=hh, wd=ww, eps=1e-5,
+                             partition_samples=n)
+        both = ops.conv3x3_gn(xa, dv(gamma), dv(beta), wp, x2=xb, bias=dv(b), residual=dv(res), groups=32, n_img=n, h=hh, wd=ww, eps=1e-5,
+                              partition_samples=n)
+        assert torch.equal(one, both[S:2 * S])
+
+
 def _tconv_gn_ref(x5, gamma, beta, w, b, res, eps=1e-5):
     """fp32 statement of one link of TemporalConvLayer's chain: GroupNorm(32) over (C/32, F, h, w) jointly,
     SiLU, Conv3d (3,1,1) with zero padding in time — every op output rounded to fp16 as the reference's fp16 modules do."""
@@ -1172,7 +1226,13 @@ def test_fused_kernels_with_wide_gamma_and_beta(gpu):
     out = ops.groupnorm_linear(x.reshape(-1, C).half().to(gpu), gamma.half().to(gpu), beta.half().to(gpu), w.half().to(gpu),
                                b.half().to(gpu), groups=32, n_samples=n_samples, rows_per_sample=rps, eps=1e-6)
     close(out, ref, tol=6e-3)
-    # K3 applies the affine in fp32 (no fold): the same affine through it
+    # K1 / K3 apply the affine in fp32 (no fold): the same affine through them
+    xi = h(torch.randn(2, C, 6, 32, generator=g) * 1.5)
+    wc = h(torch.randn(320, C, 3, 3, generator=g) / math.sqrt(9 * C) / 8)
+    ref = packing.nchw_to_rows(F.conv2d(h(F.silu(h(F.group_norm(xi, 32, gamma, beta, 1e-5)))), wc, padding=1))
+    out = ops.conv3x3_gn(packing.nchw_to_rows(xi).half().to(gpu), gamma.half().to(gpu), beta.half().to(gpu),
+                         packing.pack_conv3x3(wc.half()).to(gpu), groups=32, n_img=2, h=6, wd=32, eps=1e-5)
+    close(out, ref, tol=6e-3)
     S, Co = 32, 320
     x5 = h(torch.randn(1, C, 16, S, 1, generator=g) * 1.5)
     wt = h(torch.randn(Co, C, 3, 1, 1, generator=g) / math.sqrt(3 * C) / 8)
