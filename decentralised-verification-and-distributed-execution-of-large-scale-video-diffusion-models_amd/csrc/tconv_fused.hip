@@ -105,9 +105,15 @@ __global__ __launch_bounds__(512) void tconv_gn_kernel(const TcP p) {
                 const f16x8 v = *q;
                 f16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = (float)v[j] * a[j] + sh[j];
-                    o[j] = (f16)(y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * y)));
+                for (int j = 0; j < 8; j += 2) {      // channel pairs: v_pk_fma / v_pk_mul / v_pk_add_f32
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 x = {(float)v[j], (float)v[j + 1]};
+                    const f32x2 y = x * (f32x2){a[j], a[j + 1]} + (f32x2){sh[j], sh[j + 1]};
+                    const f32x2 u = y * -1.44269504088896341f;
+                    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
+                    const f32x2 r = y * (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                    o[j] = (f16)r[0];
+                    o[j + 1] = (f16)r[1];
                 }
                 *q = o;
             }
