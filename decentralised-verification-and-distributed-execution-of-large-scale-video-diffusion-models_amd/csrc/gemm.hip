@@ -168,6 +168,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr bool KS = VAR == 1;
+#ifdef VDX_GEMM_PLAIN_LOOP                  // timing build (tools/gemm_abl.sh): the K loop without the rolling fragment prefetch
+    constexpr bool defined_gemm_plain_loop = true;
+#else
+    constexpr bool defined_gemm_plain_loop = false;
+#endif
     typedef Stager<BM, BN, NT, MODE, SPLIT, VAR == 2> Stage;
     constexpr int STAGE = Stage::STAGE;
     static_assert(TN % 2 == 0, "tile shape");
@@ -228,6 +233,83 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmP p) {
 #endif
         const char* As = smem + cur * STAGE;
         const char* Bs = As + BM * 128;
+#if !defined(VDX_STAMPS) || VDX_ABL == 7       // (the stamped builds keep the plain loop below unless ablation 7 asks for this one)
+        if constexpr (TM == 4 && TN == 10 && !defined_gemm_plain_loop) {
+            // ---- the 64x160 wave tile: ROLLING fragment prefetch.  A K half is two groups of 20 MFMAs (column tiles 0-4, 5-9)
+            // walked column-major, so a weight fragment is dead after four MFMAs and the read of the fragment that takes its
+            // place — the next group's, the next K half's — is issued right behind them, into the same registers: the LDS
+            // latency of all but the K tile's first nine reads (nothing can be read before the barrier) and the four
+            // activation fragments of the second K half (SPLIT: the nine of either K half) runs under MFMAs.  hipcc on its own reads a group's fragments,
+            // drains the LDS queue, issues the 20 MFMAs, four times per K tile; the order here is pinned by
+            // sched_group_barrier.  Same MFMAs on the same accumulators in the same K order: same bits.
+            f16x8 af[TM], bf[5];
+            const int arow = (wm * WTM + frow) * 128, brow = (wn * WTN + frow) * 128, sw = frow & 7;   // (tile rows are multiples of 16: row & 7 = frow & 7)
+            auto rdA = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(As + arow + i * 2048 + (((ks * 4 + fq) ^ sw) << 4));
+            };
+            auto rdB = [&](int j, int ks, int g) __attribute__((always_inline)) {
+                bf[j] = *(const f16x8*)(Bs + brow + (g * 5 + j) * 2048 + (((ks * 4 + fq) ^ sw) << 4));
+            };
+            auto mm4 = [&](int j, int g) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][g * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][g * 5 + j], 0, 0, 0);
+            };
+            rdA(0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) rdB(j, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                mm4(j, 0);
+                rdB(j, 0, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if constexpr (!SPLIT) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    mm4(j, 1);
+                    rdB(j, 1, 0);
+                }
+                rdA(1);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            } else {
+                // (the gathers' weight-staging waves issue their DMA between the K halves: no fragment is carried across —
+                // the staging descriptors and 36 live fragment registers do not fit beside the accumulators)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) mm4(j, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                if (more && does_w) sg.issue_w(p, smem, cur ^ 1);
+                rdA(1);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) rdB(j, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                mm4(j, 0);
+                rdB(j, 1, 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) mm4(j, 1);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+        } else
+#endif
 #if defined(VDX_STAMPS) && VDX_ABL == 1         // diagnostic ablation 1: DMA only, no LDS reads / MFMA
         if (false)
 #endif
