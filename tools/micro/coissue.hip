@@ -159,6 +159,54 @@ __device__ __forceinline__ void role_body(int iters, float* sink) {
         for (int i = 0; i < 32; ++i) s += (float)pk[i];
         for (int i = 0; i < 8; ++i) s += acc[i][lane & 15];
         *sink = s;
+    } else if (role == 33) {
+        // (role 33: the same with 64 v_mfma_f32_16x16x32_f16 — the same flops, a quarter of the accumulator registers per instruction)
+        // ONE wave carrying both: the tile's 164 vector instructions with its 32 MFMAs spliced in, one MFMA per ~5 vector
+        // instructions (inline asm on both sides, so the order below is the issue order): does a wave's own vector work run
+        // in the shadow of its own MFMAs?  (per tile: MFMA 1024 cycles, vector mix ~1240 alone)
+        float sc[64];
+        for (int i = 0; i < 64; ++i) sc[i] = lane * 0.001f + i * 0.01f;
+        float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+        unsigned pk[32];
+        f16x8 a, b;
+        for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(lane * 0.01f + e); b[e] = (_Float16)(e * 0.25f - lane * 0.003f); }
+        f32x4 acc[16];
+        for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define MF1_(k) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[(k) & 15]) : "v"(a), "v"(b))
+#define MF_(k) do { MF1_(2 * (k)); MF1_(2 * (k) + 1); } while (0)
+        for (int it = 0; it < iters; ++it) {
+            float m0 = -1e30f, m1 = -1e30f, m2 = -1e30f, m3 = -1e30f;
+#pragma unroll
+            for (int i = 0; i < 64; i += 8) {
+                if (i < 48) MF_(i >> 3);                 // 6 MFMAs among the 34 max instructions
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m0) : "v"(sc[i]), "v"(sc[i + 1]));
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m1) : "v"(sc[i + 2]), "v"(sc[i + 3]));
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m2) : "v"(sc[i + 4]), "v"(sc[i + 5]));
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m3) : "v"(sc[i + 6]), "v"(sc[i + 7]));
+            }
+            asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m0) : "v"(m1), "v"(m2));
+            asm volatile("v_max_f32 %0, %0, %1" : "+v"(m0) : "v"(m3));
+#pragma unroll
+            for (int i = 0; i < 64; i += 2) {
+                float x, y;
+                if ((i >> 1) % 5 != 4 || i == 58) MF_(i >> 1);     // 26 MFMAs among the 128 exp / cvt / dot2c
+                asm volatile("v_exp_f32 %0, %1" : "=v"(x) : "v"(sc[i]));
+                asm volatile("v_exp_f32 %0, %1" : "=v"(y) : "v"(sc[i + 1]));
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[i >> 1]) : "v"(x), "v"(y));
+                if ((i & 6) == 0) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(l0) : "v"(pk[i >> 1]), "v"(0x3c003c00u));
+                else if ((i & 6) == 2) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(l1) : "v"(pk[i >> 1]), "v"(0x3c003c00u));
+                else if ((i & 6) == 4) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(l2) : "v"(pk[i >> 1]), "v"(0x3c003c00u));
+                else asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(l3) : "v"(pk[i >> 1]), "v"(0x3c003c00u));
+            }
+            sc[0] += m0 * 1e-30f;
+        }
+#undef MF_
+#undef MF1_
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        float s = l0 + l1 + l2 + l3;
+        for (int i = 0; i < 32; ++i) s += (float)pk[i];
+        for (int i = 0; i < 16; ++i) s += acc[i][lane & 3];
+        *sink = s;
     } else if (role == 24) {
         // the vector segment's instruction mix per 64-key tile: 36 v_max3 (4 chains) + 64 v_exp + 32 v_cvt_pk + 32 v_dot2c (4 chains),
         // on 64 distinct "score" registers as in flash.hip
@@ -275,7 +323,7 @@ __global__ __launch_bounds__(512) void k(int itA, int itB, unsigned long long* c
 
 static const char* NAMES[] = {"idle", "mfma 32x32x16", "v_exp_f32", "v_fma_f32", "v_cvt_pk_f16_f32", "v_dot2c 1 chain", "v_dot2c 4 chains",
                               "v_max3 1 chain", "v_max3 4 chains", "mfma 16x16x32", "ds_read_b128 x8", "v_cvt_pkrtz_f16_f32", "v_exp_f16", "v_pk_add_f16", "v_pk_mul_f32", "v_max_f32",
-                              "v_pk_max_f16", "v_dot2_f32_f16 16ch", "v_perm_b32", "v_cvt_f16_f32", "v_mov_b32", "v_add_f32", "v_pk_fma_f16", "v_exp_f32 indep", "softmax mix x164", "?", "mfma 32x32x16 agpr", "softmax batched x164", "mfma + 16 nop", "mfma + 24 nop", "mix @prio 3", "mfma + 28 nop", "mix + own 32 mfma"};
+                              "v_pk_max_f16", "v_dot2_f32_f16 16ch", "v_perm_b32", "v_cvt_f16_f32", "v_mov_b32", "v_add_f32", "v_pk_fma_f16", "v_exp_f32 indep", "softmax mix x164", "?", "mfma 32x32x16 agpr", "softmax batched x164", "mfma + 16 nop", "mfma + 24 nop", "mix @prio 3", "mfma + 28 nop", "mix + own 32 mfma", "mix + own 64 mfma16"};
 
 template <int roleA, int roleB>
 static void run(int itA, int itB) {
@@ -301,7 +349,7 @@ static void run(int itA, int itB) {
     std::sort(a.begin(), a.end());
     std::sort(b.begin(), b.end());
     const double ma = a[a.size() / 2], mb = b[b.size() / 2];
-    const double nA = roleA ? (roleA == 24 || roleA == 27 || roleA == 30 || roleA == 32 ? 164.0 : 64.0) * itA : 1, nB = roleB ? (roleB == 24 || roleB == 27 || roleB == 30 || roleB == 32 ? 164.0 : 64.0) * itB : 1;
+    const double nA = roleA ? (roleA == 24 || roleA == 27 || roleA == 30 || roleA == 32 || roleA == 33 ? 164.0 : 64.0) * itA : 1, nB = roleB ? (roleB == 24 || roleB == 27 || roleB == 30 || roleB == 32 || roleB == 33 ? 164.0 : 64.0) * itB : 1;
     printf("A %-18s B %-18s : A %7.2f cyc/instr   B %7.2f cyc/instr   (%.3f ms; clock ~%.2f GHz)\n", NAMES[roleA], NAMES[roleB],
            roleA ? ma / nA : 0.0, roleB ? mb / nB : 0.0, ms, std::max(ma, mb) / ms / 1e6);
     hipFree(cyc); hipFree(out);
@@ -314,6 +362,7 @@ int main(int argc, char** argv) {
 #define MF(r) run<1, r>(N, N)
     if (argc > 5) {           // a wave's own vector work in the shadow of its own MFMAs (per tile = 164 x the printed figure)
         run<24, 0>(N, 0); run<32, 0>(N, 0); run<32, 32>(N, N); run<1, 0>(N / 2, 0);
+        run<33, 0>(N, 0); run<33, 33>(N, N); run<9, 0>(N, 0);
         return 0;
     }
     if (argc > 4) {           // paced MFMA streams (s_nop behind every MFMA) and priorities beside the softmax mix
