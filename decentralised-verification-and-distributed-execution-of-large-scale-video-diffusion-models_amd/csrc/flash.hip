@@ -29,6 +29,28 @@
 //   FL_ABL_NOEXP / NOSUM / NOMAX / NODMA / NOKREAD / NOVREAD / NOBAR   timing-only builds with one part of the tile
 //       removed (WRONG RESULTS by construction) — profiles/r04_flash.md's ablation table;
 //   FL_STAMPS   per-wave s_memtime sums of the tile's phases into g_fl_stamps (read back with vdx_flash_stamps_read).
+//   FL_ABL_MFMA16   timing-only: every 32x32x16 MFMA issued as two 16x16x32 on quarters of its accumulator (the same flops; WRONG
+//       RESULTS) — what the tile costs on the shape the chip clocks higher on (profiles/r04_flash.md §11).
+#ifdef FL_ABL_MFMA16
+template <int SEL>
+__device__ __forceinline__ f32x16 fl_mfma(const f16x8 a, const f16x8 b, f32x16 c) {
+    f32x4 q0 = __builtin_shufflevector(c, c, 8 * SEL, 8 * SEL + 1, 8 * SEL + 2, 8 * SEL + 3);
+    f32x4 q1 = __builtin_shufflevector(c, c, 8 * SEL + 4, 8 * SEL + 5, 8 * SEL + 6, 8 * SEL + 7);
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q1, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c[8 * SEL + e] = q0[e];
+        c[8 * SEL + 4 + e] = q1[e];
+    }
+    return c;
+}
+#else
+template <int SEL>
+__device__ __forceinline__ f32x16 fl_mfma(const f16x8 a, const f16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+#endif
 #ifdef FL_STAMPS
 static __device__ unsigned long long g_fl_stamps[8 * 32768];     // [block * waves + wave][8]: four phase sums, total, tiles
 #define FL_T(i)                                                     \
@@ -369,7 +391,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 #endif
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
-                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], ks == 0 ? zero16 : s_acc[qb][kb], 0, 0, 0);
+                    s_acc[qb][kb] = (ks & 1) ? fl_mfma<1>(kf, qf[qb][ks], s_acc[qb][kb]) : fl_mfma<0>(kf, qf[qb][ks], ks == 0 ? zero16 : s_acc[qb][kb]);
             }
             if (st.offset_on) {
 #pragma unroll
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
 #endif
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
-                    o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kk], o_acc[qb][db], 0, 0, 0);
+                    o_acc[qb][db] = (kk & 1) ? fl_mfma<1>(vf, pf[qb][kk], o_acc[qb][db]) : fl_mfma<0>(vf, pf[qb][kk], o_acc[qb][db]);
             }
         }
         FL_T(2);
