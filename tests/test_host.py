@@ -227,6 +227,20 @@ def test_gemm_plan_is_host_only_and_splits_the_mostly_idle_last_round():
         assert lib.vdx_gemm_plan(C.byref(g), C.byref(v), C.byref(s)) != 0 and b"rows [" in lib.vdx_last_error(), bad
 
 
+def test_fused_conv_predicates_are_host_only_and_state_their_limits():
+    """K1 / K3's `supported` / `preferred` entry points answer without a GPU (the UNet asks them per layer): widths in 64-channel
+    slices, 320-column tiles, K1's per-picture scale / shift table bounded by the LDS left beside the tiles (C1 + C2 <= 1536),
+    K3's frame chunk a divisor of the clip (16 / 12 / 8)."""
+    lib = _lib.load()
+    assert lib.vdx_conv3x3_gn_supported(320, 0, 320) == 1 and lib.vdx_conv3x3_gn_supported(640, 320, 320) == 1
+    assert lib.vdx_conv3x3_gn_supported(960, 576, 320) == 1 and lib.vdx_conv3x3_gn_supported(1280, 0, 1280) == 1
+    assert lib.vdx_conv3x3_gn_supported(1280, 1280, 1280) == 0          # 2560 input channels: the table does not fit
+    assert lib.vdx_conv3x3_gn_supported(320, 0, 4) == 0 and lib.vdx_conv3x3_gn_supported(100, 0, 320) == 0
+    assert lib.vdx_conv3x3_gn_supported(320, 40, 320) == 0
+    assert lib.vdx_tconv_gn_supported(320, 320, 24) == 1 and lib.vdx_tconv_gn_supported(1280, 1280, 16) == 1
+    assert lib.vdx_tconv_gn_supported(320, 320, 20) == 0 and lib.vdx_tconv_gn_supported(320, 256, 16) == 0
+
+
 def test_split_k_is_not_taken_by_any_product_of_the_xl_forward():
     """whether a product runs its tail as split-K (a different summation order) depends on its row count, so a
     sample's bits could depend on the window length.  Pinned here: for every GEMM the XL UNet calls with allow_ksplit
