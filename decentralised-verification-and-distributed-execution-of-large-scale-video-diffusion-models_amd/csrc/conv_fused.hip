@@ -12,14 +12,16 @@
 // The temporal sibling is K3 (tconv_fused.hip); the structure is the same.  Tile = a patch of 6 x 32 pixels of ONE image x
 // 320 output channels (192 rows, rows ordered (y, x)).  Per 64-channel slice the block stages ONE image of the patch and its
 // one-pixel halo — 8 x 34 pixels x 64 channels, 34 KB — by LDS-DMA (zero page outside the image), normalises it IN PLACE in
-// LDS (once per element, not once per tap) while the previous slice's last tap runs on the matrix cores, and the nine taps
+// LDS (once per element, not once per tap) in five 64-row pieces during taps 4..8 of the slice before, and the nine taps
 // read their activation fragments from that one image at row offsets (ky * 34 + kx).  A fragment's 16 lanes read 16
 // consecutive image columns; the 16-byte chunk swizzle is the image COLUMN's low three bits, so a tap's swizzle depends on kx
 // alone and a fragment address is one add on precomputed lane offsets.  Weights per (slice, tap) as [320][64] tiles,
 // double-buffered, in gemm.hip's layout / swizzle / row permutation (the same packed weights: K = (c / 64) * 576 + tap * 64 +
 // c % 64); accumulators, weight fragments and the 16-byte epilogue stores are gemm.hip's.
 // LDS: 2 x 34 KB (image) + 2 x 40 KB (weights) + 8 bytes per input channel (scale, shift) <= 160 KB, one 512-thread
-// block per CU.
+// block per CU.  Measurements, the three versions of this kernel and what the in-LDS normalisation costs: profiles/r04_k1.md.
+// Diagnostic switches (tools/k1_abl.sh builds them into csrc/build/abl/libk1_<tag>.so; the product defines none):
+//   K1_ABL_NONORM  timing-only, WRONG RESULTS: later slices are not normalised;   K1_ABL_NOPIN  hipcc's own instruction order.
 #include "gemm_common.h"
 
 struct C1P {

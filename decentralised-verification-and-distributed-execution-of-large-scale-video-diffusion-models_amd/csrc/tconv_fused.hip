@@ -33,7 +33,7 @@ struct TcP {
 
 template <int FT>
 __global__ __launch_bounds__(512) void tconv_gn_kernel(const TcP p) {
-    constexpr int BN = 320, WM = 4, WN = 2, NT = 512;
+    constexpr int BN = 320, WM = 4, WN = 2;
     constexpr int TM = FT / WM, TN = BN / WN / 16;           // a wave: TM frames (row tiles of 16 pixels) x 160 columns
     constexpr int IROWS = (FT + 2) * 16, IMG = IROWS * 128, WT = BN * 128;
     constexpr int IK = (IROWS + 63) / 64;                    // DMA instructions per thread slot for one image
