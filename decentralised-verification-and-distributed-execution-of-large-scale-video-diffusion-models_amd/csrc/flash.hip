@@ -23,8 +23,6 @@
 // a SIMD in alternating matrix / vector segments (a 512-thread "ping-pong" kernel, built in round 4, bit-identical, commit
 // "flash: ping-pong kernel experiment") is not faster: beside a wave that streams MFMAs, the softmax's vector mix is all
 // but starved, whichever wave is older or has the priority.
-#include <cstdlib>
-
 #include "attn_common.h"
 
 // Diagnostic switches (tools/flash_abl.sh builds them into csrc/build/abl/libflash_<tag>.so; the product defines none):
@@ -463,281 +461,6 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashP p) {
     fl_store<QB>(p, st, o_acc, seq, head, q0, r32, h);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// flash16: the same algorithm (lazy monotone offset, fp16 P, fp32 sums, identical staging traffic) on
-// v_mfma_f32_16x16x32_f16, for the long spatial self-attention launches (V as rows, no mask).  The chip holds a higher clock
-// on this shape than on 32x32x16 beside the softmax's vector work (profiles/r04_flash.md §11).
-// With n = lane & 15, g = lane >> 4:
-//   S^T tile (key tile kt of 16, query tile qt of 16) = K frag (A: row m = n, k = d 32 ds + 8 g ..) x Q frag (B: column n);
-//   the accumulator holds rows 4 g + j, and row m of key tile kt is made key  32 (kt >> 1) + 8 (m >> 2) + 4 (kt & 1) + (m & 3)
-//   by the row each lane reads its K fragment from, so that a lane's eight values of key tiles 2 u, 2 u + 1 are keys
-//   32 u + 8 g + 0..7 of its query IN ORDER = its B operand of O^T += V^T . P^T for the 32-key step u, with no shuffle;
-//   V^T frag (A: row = d 16 dt + n, k = keys 32 u + 8 g ..) by two ds_read_b64_tr_b16 from the V rows in LDS;
-//   O^T tile (dt, qt): lane holds d = 16 dt + 4 g + j of query 16 qt + n.
-// A query's 64 keys of a tile are spread over the four lane groups: the row maximum takes two lane exchanges (16, 32).
-// LDS images: K row r, 16-byte slot s holds data chunk s ^ fK(r), fK = ((r >> 1) & 1) | (((r >> 3) & 3) << 1): the 16 lanes
-// of a ds_read_b128 bank group (MI355X_MICROARCH.md §LDS) then hit 16 distinct (row parity, slot) pairs; V row r slot s
-// holds chunk s ^ fV(r), fV = (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2): the 32 lanes of a transposed read 32 distinct
-// 8-byte words.
-__device__ __forceinline__ float fl16_quad_max(float v) {
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    a = fmaxf(a, b);
-    b = a;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
-}
-__device__ __forceinline__ int fl16_key(int kt, int g, int j) { return 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + j; }
-
-__global__ __launch_bounds__(256) void flash16_kernel(const FlashP p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    int pair, qblk;
-    fl_block_map(p, pair, qblk);
-    const int head = pair % p.heads, seq = pair / p.heads;
-    const int kvb = seq / p.seq_per_kv;
-    const int q0 = (qblk * 4 + wave) * 64;
-
-    // Q fragments (B operand of S^T), pre-scaled
-    f16x8 qf[4][2];
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        const int qr = min(q0 + 16 * qt + n, p.sq - 1);
-        const f16* src = p.q + ((size_t)seq * p.sq + qr) * p.ldq + head * 64 + 8 * g;
-#pragma unroll
-        for (int ds = 0; ds < 2; ++ds) {
-            const f16x8 raw = *(const f16x8*)(src + 32 * ds);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[qt][ds][j] = (f16)((float)raw[j] * p.c);
-        }
-    }
-
-    // ---- staging: as flash_attn_kernel (2 K pieces + 2 V pieces per wave and tile), the two swizzles above
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const f16* zp = (const f16*)g_zero_page;
-    const int st_row0 = tid >> 3, st_row1 = st_row0 + 32;              // (+32 changes neither swizzle)
-    const int chk = (tid & 7) ^ (((st_row0 >> 1) & 1) | (((st_row0 >> 3) & 3) << 1));
-    const int chv = (tid & 7) ^ ((((st_row0 >> 1) & 1) << 1) | (((st_row0 >> 3) & 1) << 2));
-    const f16* kptr0 = p.k + ((size_t)kvb * p.skv_pad + st_row0) * p.ldk + head * 64 + chk * 8;
-    const f16* kptr1 = p.k + ((size_t)kvb * p.skv_pad + st_row1) * p.ldk + head * 64 + chk * 8;
-    const f16* vptr0 = p.vt + ((size_t)kvb * p.skv_pad + st_row0) * p.ldvt + head * 64 + chv * 8;
-    const f16* vptr1 = p.vt + ((size_t)kvb * p.skv_pad + st_row1) * p.ldvt + head * 64 + chv * 8;
-    const size_t kstep = (size_t)64 * p.ldk, vstep = (size_t)64 * p.ldvt;
-    auto issue = [&](int t, int buf) {
-        char* sk = smem + buf * 16384 + wv * 1024;
-        const int k0 = t * 64;
-        const f16 *k0p = kptr0, *k1p = kptr1, *v0p = vptr0, *v1p = vptr1;
-        if (k0 + 64 > p.skv_pad) {                                    // tile crosses skv_pad (wave-uniform)
-            if (k0 + st_row0 >= p.skv_pad) k0p = v0p = zp;
-            if (k0 + st_row1 >= p.skv_pad) k1p = v1p = zp;
-        }
-        __builtin_amdgcn_global_load_lds((fl_gptr_t)k0p, (fl_lptr_t)sk, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((fl_gptr_t)k1p, (fl_lptr_t)(sk + 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((fl_gptr_t)v0p, (fl_lptr_t)(sk + 8192), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((fl_gptr_t)v1p, (fl_lptr_t)(sk + 8192 + 4096), 16, 0, 0);
-        kptr0 += kstep;
-        kptr1 += kstep;
-        vptr0 += vstep;
-        vptr1 += vstep;
-    };
-
-    // ---- fragment addressing
-    // K: my A row n of key tile kt is LDS row  8 (n >> 2) + (n & 3) + 32 (kt >> 1) + 4 (kt & 1);  fK of it = ((n >> 1) & 1) | ((n >> 2) << 1)
-    const int fk = ((n >> 1) & 1) | ((n >> 2) << 1);
-    const int kb0 = (8 * (n >> 2) + (n & 3)) * 128 + ((g ^ fk) << 4);         // d step 0; d step 1 = chunk 4 + g: ^ 64
-    // V: lane i = 4 q + pp of its 16-lane group addresses key row 8 g + q (+ 4 for the upper half of the operand, + 32 u),
-    // d columns 16 dt + 4 pp .. + 3  = chunk 2 dt + (pp >> 1), byte 8 (pp & 1)
-    const int vq = n >> 2, vp = n & 3;
-    const int fv = ((vq >> 1) << 1) | ((g & 1) << 2);
-    const int vb0 = (8 * g + vq) * 128 + 8 * (vp & 1);
-    int voff[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) voff[dt] = vb0 + ((((2 * dt) ^ fv) | (vp >> 1)) << 4);
-
-    // ---- state
-    f32x4 o_acc[4][4];
-    float r_run[4], r_part[4], l_run[4][2];
-    bool settled = false;
-    f16x8 negm[4];
-    bool offset_on = false;
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        r_run[qt] = r_part[qt] = NEG_BIG;
-        l_run[qt][0] = l_run[qt][1] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) negm[qt][j] = (f16)0.0f;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o_acc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    f16x8 e0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e0[j] = (f16)((j == 0 && g == 0) ? 1.0f : 0.0f);
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f16x2 one2;
-    one2[0] = one2[1] = (f16)1.0f;
-
-    const int ntiles = (p.skv + 63) >> 6;
-    issue(0, 0);
-    __syncthreads();                       // LDS-DMA in flight: the barrier's fence waits vmcnt(0)
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntiles) issue(t + 1, cur ^ 1);   // buffer cur^1 was last read before the previous barrier
-        const char* Ks = smem + cur * 16384;
-        const char* Vs = Ks + 8192;
-        const int k0 = t * 64;
-
-        // ---- S' = K . Q^T - m
-        f32x4 s_acc[4][4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-                const f16x8 kf = *(const f16x8*)(Ks + (kb0 ^ (ds << 6)) + (32 * (kt >> 1) + 4 * (kt & 1)) * 128);
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
-                    s_acc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ds], ds == 0 ? zero4 : s_acc[qt][kt], 0, 0, 0);
-            }
-        if (offset_on) {                   // (one block behind the 32 MFMAs above: a branch per key tile would fence their fragment reads)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
-                    s_acc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e0, negm[qt], s_acc[qt][kt], 0, 0, 0);   // - m
-        }
-        if (k0 + 64 > p.skv) {
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k0 + fl16_key(kt, g, j) >= p.skv) s_acc[qt][kt][j] = NEG_BIG;
-        }
-
-        // ---- row maxima and the lazy offset (FlSoft's rules, per query tile)
-        // r_part: the running maximum over MY keys of the row (a quarter of them).  The window test needs the row's true running
-        // maximum only (a) until it is known to be >= -4 — it never falls, so that is settled after the first unmasked tile
-        // (`settled`, wave-uniform) — and (b) when some lane's part exceeds 10, i.e. when the offset has to move: the two lane
-        // exchanges run then, not in every tile, and give exactly the maximum an every-tile exchange would have kept.
-        bool move[4], any_move = false;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int j = 0; j < 4; j += 2)
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) r_part[qt] = fmaxf(fmaxf(r_part[qt], s_acc[qt][kt][j]), s_acc[qt][kt][j + 1]);
-        bool look = !settled;
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) look |= r_part[qt] > 10.0f;
-        if (__builtin_amdgcn_ballot_w64(look) != 0) {                // first tile(s), and tiles in which an offset may have to move
-            bool low = false;
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                r_run[qt] = fl16_quad_max(r_part[qt]);
-                move[qt] = (fabsf(r_run[qt] - 3.0f) > 7.0f) & (r_run[qt] > -1.0e29f);
-                any_move |= move[qt];
-                low |= r_run[qt] < -4.0f;                            // (also "every tile so far masked")
-            }
-          if (__builtin_amdgcn_ballot_w64(any_move) != 0) {          // rare
-            bool nonzero = false;
-            low = false;
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                const float m_old = -(float)negm[qt][0];
-                const float tgt = fminf(fmaxf(m_old + (move[qt] ? r_run[qt] : 0.f), -60000.0f), 60000.0f);
-                const float m_new = (float)(f16)tgt;
-                const float d = m_new - m_old;                       // shift actually applied
-                negm[qt][0] = (f16)(-m_new);
-                r_run[qt] -= d;
-                r_part[qt] -= d;
-                const float alpha = d > 0.f ? __builtin_amdgcn_exp2f(-d) : 1.0f;   // d < 0: first move, O = l = 0
-                l_run[qt][0] *= alpha;
-                l_run[qt][1] *= alpha;
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        s_acc[qt][x][j] -= d;
-                        o_acc[qt][x][j] *= alpha;
-                    }
-                nonzero |= m_new != 0.f;
-                low |= r_run[qt] < -4.0f;
-            }
-            offset_on = __builtin_amdgcn_ballot_w64(nonzero) != 0;
-          }
-          settled = __builtin_amdgcn_ballot_w64(low) == 0;
-        }
-
-        // ---- per 32-key step u: the step's four V^T fragments; per query tile 8 x exp2(S') -> fp16 pairs = its P^T operand
-        // (element 4 (kt & 1) + j), row sums by dot2, and at once the four MFMAs O^T[dt] += V^T[dt] . P^T that consume it
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f16x8 vf[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                typedef short s16x4v __attribute__((__vector_size__(8)));
-                typedef __attribute__((address_space(3))) s16x4v* ltr_t;
-                struct TrPair { s16x4v lo, hi; } pr;
-                const char* vb = Vs + voff[dt] + u * 4096;
-                pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)vb);
-                pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(vb + 512));
-                vf[dt] = __builtin_bit_cast(f16x8, pr);
-            }
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                f16x8 pf;
-#pragma unroll
-                for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        f16x2 pp;
-                        pp[0] = (f16)__builtin_amdgcn_exp2f(s_acc[qt][2 * u + kh][j]);
-                        pp[1] = (f16)__builtin_amdgcn_exp2f(s_acc[qt][2 * u + kh][j + 1]);
-                        l_run[qt][(j >> 1) & 1] = __builtin_amdgcn_fdot2(pp, one2, l_run[qt][(j >> 1) & 1], false);
-                        pf[4 * kh + j] = pp[0];
-                        pf[4 * kh + j + 1] = pp[1];
-                    }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt], pf, o_acc[qt][dt], 0, 0, 0);
-            }
-        }
-        // issue order of the eight (step, query tile) units: unit i's four MFMAs beside unit i + 1's exponentials / packs /
-        // sums (left alone hipcc issues all 64 exponentials first and the 32 MFMAs behind them: nothing in their shadow)
-        __builtin_amdgcn_sched_group_barrier(0x400, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-#pragma unroll
-        for (int unit = 0; unit < 7; ++unit)
-#pragma unroll
-            for (int m_ = 0; m_ < 4; ++m_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __syncthreads();                   // next tile landed (vmcnt(0)) and this one is fully read
-    }
-
-    // ---- epilogue: O[query][d], lane = query 16 qt + n, d = 16 dt + 4 g + (0..3): 8-byte stores
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        float l = l_run[qt][0] + l_run[qt][1];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
-        const int qrow = q0 + 16 * qt + n;
-        f16* dst = p.out + ((size_t)seq * p.sq + qrow) * p.ldo + head * 64 + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            f16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (f16)(o_acc[qt][dt][j] * inv);
-            if (qrow < p.sq) *(f16x4*)(dst + 16 * dt) = o;
-        }
-    }
-}
-
 template <bool VROW>
 static int flash_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                         void* out, int ldo, int n_seq, int sq, int skv, int skv_pad, int heads,
@@ -762,15 +485,6 @@ static int flash_launch(const void* q, int ldq, const void* k, int ldk, const vo
     p.xcd = p.npairs % 8 == 0 ? 1 : 0;
     p.nqb = two ? (sq + 255) / 256 : (sq + 127) / 128;
     VDX_CHECK((long long)p.nqb * p.npairs < (1ll << 31), "flash_attn: grid too large");
-#ifdef FL16_DEFAULT
-    const bool use16 = true;
-#else
-    static const bool use16 = getenv("VDX_FLASH16") != nullptr;          // EXPERIMENT switch (lab only)
-#endif
-    if (two && VROW && !causal && use16) {
-        hipLaunchKernelGGL(flash16_kernel, dim3(p.nqb * p.npairs), dim3(256), 0, (hipStream_t)stream, p);
-        return vdx_launch_status("vdx_flash_attn_rows_f16 (16x16x32)");
-    }
     if (two) {
         dim3 grid(p.nqb * p.npairs);
         if (causal) hipLaunchKernelGGL((flash_attn_kernel<2, true, VROW>), grid, dim3(256), 0, (hipStream_t)stream, p);
