@@ -75,6 +75,20 @@ def select_config(world, name=None):
 PEAK_MFMA_TFLOPS = 2500.0        # gfx950 dense fp16/bf16 matrix peak (MI355X_MICROARCH.md)
 
 
+def shared_prefix_tflop(frames: int, hw: int = 72 * 128) -> float:
+    """Algorithmic TFLOP (2 x MACs, SURVEY §8d's counting) of the blocks the CFG-shared prefix computes for ONE batch item
+    instead of two (unet3d.forward): conv_in, transformer_in, down_blocks.0.resnets.0 / temp_convs.0 and the first spatial
+    transformer up to the query projection of its cross-attention — the work a duplicated forward does twice.  Per
+    level-0 row (320 channels; transformer_in inner 512, 8 heads):"""
+    c, i = 320, 512
+    macs = 36 * c                                                   # conv_in (4 -> 320, 3x3)
+    macs += c * i + 2 * (4 * i * i + 2 * frames * i) + 12 * i * i + i * c      # transformer_in: proj_in, 2 x (q|k|v|out + FxF core), GEGLU FF, proj_out
+    macs += 2 * 9 * c * c                                           # ResnetBlock2D conv1 + conv2
+    macs += 4 * 3 * c * c                                           # TemporalConvLayer, four (3,1,1) convolutions
+    macs += c * c + 3 * c * c + 2 * hw * c + c * c + c * c          # spatial: proj_in, q|k|v, self-attention core, to_out, cross-attention q
+    return 2.0 * macs * frames * hw / 1e12
+
+
 def cpu_baseline(frames: int, threads: int):
     """Oracle (fp32 PyTorch-CPU restatement, kind "port") timed on this host on a bounded sample:
     one CFG UNet forward with XL-shaped weights at `frames` frames @ 576x1024; FLOPs are linear in
@@ -120,6 +134,33 @@ def copy_activity_of_a_step(step, i, lats):
         return {"step_copy_activity_error": f"{type(e).__name__}: {e}"[:200]}
 
 
+def self_launch_command(argv, n, port):
+    """The command a bare `python bench.py --gpus N` (N > 1, no launcher) re-runs itself under: one rank per GPU through
+    torch.distributed.run on 127.0.0.1 — exactly what the driver's own multi-GPU command is."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, n):
+    """Parent of a launcher-less multi-GPU run.  Nothing here touches the GPU (no HIP call, no `torch.cuda.*`): the ranks
+    are CHILD processes; rank 0's single JSON line and the launcher's exit code are relayed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL and the peer-mapped shard arenas need here
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(self_launch_command(argv, n, port), stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{") and '"metric"' in ln]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(r.stdout[-4000:])
+    raise SystemExit(r.returncode if (r.returncode or lines) else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +192,8 @@ def main():
                          "nats above the mean, as trained checkpoints have) — the lazy softmax offset of the flash kernel then "
                          "has to move; the default synthetic weights give near-uniform attention, its best case")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-duplicate-leg", action="store_true",
+                    help="skip the second timing of the same steps with the CFG-shared prefix off (`ms_per_step_full_duplicate`)")
     ap.add_argument("--rehearse-copies", action="store_true",
                     help="with --rehearse-dist --as-world N on one GPU: issue every parameter gather as N copies (the host call count of a node)")
     ap.add_argument("--profile-all", action="store_true",
@@ -168,6 +211,9 @@ def main():
     if (args.backend != "nccl" or args.share_gpu or args.frames or args.resident or args.no_lean or args.lean_parts is not None) and not args.rehearsal:
         raise SystemExit("--backend gloo, --share-gpu, --frames and --resident change what is measured: pass --rehearsal with them")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher (the driver's N = 1 command has none): become the launcher
+        self_launch(sys.argv[1:], args.gpus)
     # stdout carries exactly ONE JSON line: libraries that print to fd 1 (RCCL's version banner)
     # are sent to stderr for the whole run.
     sys.stdout.flush()
@@ -290,10 +336,26 @@ def main():
     finite = all(bool(torch.isfinite(lat.float()).all()) for lat in lats)
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     free_b, total_b = torch.cuda.mem_get_info(dev)            # device-wide (the reference's pynvml `used`, :41-45,262)
-    tt = torch.tensor([dt, peak_gb, (total_b - free_b) / 2 ** 30], device=dev, dtype=torch.float64)
+    # The same K steps once more with the CFG-shared prefix OFF (every block computes both batch items, as a forward on
+    # `torch.cat([lat]*2)` does): the line carries both times, so a reader sees what the product's default saves and that
+    # the headline is not a step with work dropped — only a duplicate (same output bits, tests/test_unet_gpu.py).
+    shared_on = bool(getattr(unet, "last_forward_shared_prefix", False))
+    dt_dup = 0.0
+    if shared_on and not args.no_duplicate_leg:
+        unet.share_cfg_prefix = False
+        lats_d = step(args.warmup + args.steps, lats)           # warm the shapes of the duplicated form
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            lats_d = step(args.warmup + i, lats_d)
+        fence()
+        dt_dup = time.perf_counter() - t0
+        unet.share_cfg_prefix = True
+        del lats_d
+    tt = torch.tensor([dt, peak_gb, (total_b - free_b) / 2 ** 30, dt_dup], device=dev, dtype=torch.float64)
     if dist_mode:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt, peak_gb, used_gb = float(tt[0]), float(tt[1]), float(tt[2])
+    dt, peak_gb, used_gb, dt_dup = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
 
     if rank == 0:
         my_frames = sum(e_ - s_ for s_, e_ in ranges)                        # frames THIS rank computes per step
@@ -322,10 +384,21 @@ def main():
             # per-device peak against the monolithic single-GPU peak at the SAME total frame count
             # (profiles/monolithic_peaks.json, measured by tools/mem_profile.py --frames T); north star: <= 0.15 at N = 8
             "peak_hbm_frac_of_monolithic": round(peak_gb / mono, 4) if mono else None,
+            # reference-equivalent FLOPs: what the reference's step computes for these frames (both CFG items in every block)
             "path_tflops_per_gpu": round(tf_step * args.steps / dt, 2),
             "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
             "output_finite": finite,
         }
+        # EXECUTED FLOPs: the shared prefix computes its blocks for one item, not two
+        saved = sum(shared_prefix_tflop(e_ - s_, H * W) for s_, e_ in ranges) if shared_on else 0.0
+        out["cfg_shared_prefix"] = shared_on
+        out["tflop_per_step_reference_equivalent"] = round(tf_step, 2)
+        out["tflop_per_step_executed"] = round(tf_step - saved, 2)
+        out["path_tflops_executed_per_gpu"] = round((tf_step - saved) * args.steps / dt, 2)
+        out["path_mfma_frac_executed"] = round((tf_step - saved) * args.steps / dt / PEAK_MFMA_TFLOPS, 4)
+        if dt_dup > 0:
+            out["ms_per_step_full_duplicate"] = round(1e3 * dt_dup / args.steps, 3)
+            out["path_mfma_frac_full_duplicate"] = round(tf_step * args.steps / dt_dup / PEAK_MFMA_TFLOPS, 4)
         if store is not None:
             # how the parameter gathers travelled, whether the peer mapping reproduced the collective (world > 1 only), and
             # what they cost the HOST: gathers per step, copies per gather, host time spent enqueueing them per step

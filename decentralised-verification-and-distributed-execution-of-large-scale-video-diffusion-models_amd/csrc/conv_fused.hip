@@ -335,8 +335,12 @@ extern "C" int vdx_conv3x3_gn_supported(int c1, int c2, int N) {
 // width the 32-pixel patches tile, and at least two tiles per CU (profiles/r04_k1.md).
 extern "C" int vdx_conv3x3_gn_preferred(int c1, int c2, int N, int n_img, int h, int w) {
     if (!vdx_conv3x3_gn_supported(c1, c2, N) || N != 320 || w % C1_PW != 0) return 0;
-    const long long tiles = (long long)n_img * ((h + C1_PH - 1) / C1_PH) * (w / C1_PW);
-    return tiles >= 2 * vdx_num_cus() ? 1 : 0;
+    // The choice is a function of ONE image's shape (not of n_img, not of the chip): K1 and the apply pass + conv GEMM differ
+    // by a rounding of the normalised value, and a sample's bits must not depend on the batch or window it is computed in
+    // (ADVICE r4).  48 tiles per image at level 0 of the XL UNet; n_img is kept in the signature for the C-ABI only.
+    (void)n_img;
+    const long long tiles_per_image = (long long)((h + C1_PH - 1) / C1_PH) * (w / C1_PW);
+    return tiles_per_image >= 32 ? 1 : 0;
 }
 
 extern "C" int vdx_conv3x3_gn_f16(const void* a, int lda, const void* a2, int lda2, int c1, int c2, const float* scale_shift,
@@ -344,6 +348,7 @@ extern "C" int vdx_conv3x3_gn_f16(const void* a, int lda, const void* a2, int ld
                                   const void* residual, int ldr, void* out, int ldo, int n_img, int h, int w_px, int N,
                                   vdx_stream_t stream) {
     VDX_CHECK(a && scale_shift && w && out, "conv3x3_gn: null pointer");
+    VDX_CHECK((uintptr_t)scale_shift % 16 == 0, "conv3x3_gn: scale_shift must be 16-byte aligned (it is read with 16-byte loads)");
     VDX_CHECK(n_img > 0 && h > 0 && w_px > 0, "conv3x3_gn: empty problem");
     VDX_CHECK(vdx_conv3x3_gn_supported(c1, c2, N), "conv3x3_gn: c1=%d c2=%d (%% 64), N=%d (%% 320) not supported", c1, c2, N);
     VDX_CHECK((c2 == 0) == (a2 == nullptr), "conv3x3_gn: a2/c2 mismatch");

@@ -228,7 +228,7 @@ static int gn_threads(int nvec, int* krows) {
 extern "C" size_t vdx_groupnorm_workspace_part(int n_samples, int rows_per_sample, int C, int G, int partition_samples) {
     const int rows = gn_stat_rows(partition_samples > 0 ? partition_samples : n_samples, rows_per_sample);
     const size_t nslabs = (rows_per_sample + rows - 1) / rows;
-    return ((size_t)n_samples * nslabs * G * 3 + (size_t)n_samples * C * 2) * sizeof(float);
+    return ((((size_t)n_samples * nslabs * G * 3 + 3) & ~(size_t)3) + (size_t)n_samples * C * 2) * sizeof(float);
 }
 extern "C" size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G) {
     return vdx_groupnorm_workspace_part(n_samples, rows_per_sample, C, G, 0);
@@ -265,7 +265,7 @@ static int gn_run(const void* x, int c1, int ldx, const void* x2, int c2, int ld
     p.apply_rows = gn_rows_for(n_samples, rows_per_sample, 1024);
     p.nslabs = (rows_per_sample + p.slab_rows - 1) / p.slab_rows;
     p.partial = (float*)workspace;
-    p.ab = p.partial + (size_t)n_samples * p.nslabs * G * 3;
+    p.ab = p.partial + (((size_t)n_samples * p.nslabs * G * 3 + 3) & ~(size_t)3);     // 16-byte aligned: K1 / K3 read it with 16-byte loads
     const int nt = gn_threads(p.nvec, &p.krows);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.nslabs, n_samples);

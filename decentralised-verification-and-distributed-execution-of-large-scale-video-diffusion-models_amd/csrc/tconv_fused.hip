@@ -217,8 +217,10 @@ extern "C" int vdx_tconv_gn_supported(int C, int N, int F) {
 // 1.16-1.25 x faster; with 2 or 4 column tiles every tile normalises the image again and it is 0.6-0.98 x.
 extern "C" int vdx_tconv_gn_preferred(int C, int N, int B, int F, int S) {
     if (!vdx_tconv_gn_supported(C, N, F) || N != 320) return 0;
-    const long long tiles = (long long)B * (F / tconv_ft(F)) * ((S + 15) / 16);
-    return tiles >= 2 * vdx_num_cus() ? 1 : 0;
+    // a function of ONE sample's shape (C, N, F, S) — not of B, not of the chip: see vdx_conv3x3_gn_preferred
+    (void)B;
+    const long long tiles_per_sample = (long long)(F / tconv_ft(F)) * ((S + 15) / 16);
+    return tiles_per_sample >= 512 ? 1 : 0;
 }
 
 template <int FT>
@@ -239,6 +241,7 @@ extern "C" int vdx_tconv_gn_f16(const void* x, int ldx, const float* scale_shift
                                 const void* residual, int ldr, void* out, int ldo, int B, int F, int S, int C, int N,
                                 vdx_stream_t stream) {
     VDX_CHECK(x && scale_shift && w && out, "tconv_gn: null pointer");
+    VDX_CHECK((uintptr_t)scale_shift % 16 == 0, "tconv_gn: scale_shift must be 16-byte aligned (it is read with 16-byte loads)");
     VDX_CHECK(B > 0 && F > 0 && S > 0, "tconv_gn: empty problem");
     VDX_CHECK(vdx_tconv_gn_supported(C, N, F), "tconv_gn: C=%d (%% 64), N=%d (%% 320), F=%d (%% 8) not supported", C, N, F);
     VDX_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && (!residual || ldr % 8 == 0) && ldx >= C && ldo >= N, "tconv_gn: leading dimensions");

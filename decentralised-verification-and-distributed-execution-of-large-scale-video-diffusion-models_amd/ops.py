@@ -78,7 +78,7 @@ def groupnorm_linear(x, gamma, beta, w, bias, *, groups, n_samples, rows_per_sam
     if not groupnorm_linear_supported(Cc, N, rows_per_sample) or not w.is_contiguous():
         raise VdxError(f"groupnorm_linear: C={Cc}, N={N}, rows_per_sample={rows_per_sample} not supported")
     need = lib.vdx_groupnorm_workspace_part(n_samples, rows_per_sample, Cc, groups, partition_samples)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
@@ -338,7 +338,7 @@ def groupnorm(x, gamma, beta, *, groups, n_samples, rows_per_sample, eps, silu_a
     if orow < M or ocol < Cc:
         raise VdxError("groupnorm: out too small")
     need = lib.vdx_groupnorm_workspace_part(n_samples, rows_per_sample, Cc, groups, partition_samples)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
@@ -398,7 +398,7 @@ def conv3x3_gn(x, gamma, beta, w, *, x2=None, bias=None, bias2=None, rows_per_bi
     if orow < M or ocol < N:
         raise VdxError("conv3x3_gn: out too small")
     need = lib.vdx_groupnorm_workspace_part(n_img, S, Cc, groups, partition_samples)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
@@ -457,7 +457,7 @@ def tconv_gn(x, gamma, beta, w, *, bias=None, residual=None, groups, B, F, S, ep
     if orow < M or ocol < N:
         raise VdxError("tconv_gn: out too small")
     need = lib.vdx_groupnorm_workspace_part(B, F * S, Cc, groups, partition_samples)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
@@ -687,7 +687,18 @@ def cfg_input(lat, ctx, weight, out=None):
         out = torch.empty((2, Cc, F, H, W), dtype=torch.float16, device=lat.device)
     _lib.check(lib.vdx_cfg_input_f16(_p(lat, "lat"), _p(ctx, "ctx"), float(weight), _p(out, "out"), Cc, F, H * W,
                                      _stream()), "vdx_cfg_input_f16")
+    out._vdx_cfg_dup = out._version        # both batch items hold the same values until somebody writes the tensor
     return out
+
+
+def is_cfg_duplicate(x) -> bool:
+    """True for a tensor `cfg_input` produced and nobody has written since (torch's version counter): its two batch items
+    are known to be equal, which lets the UNet compute the text-independent blocks once (unet3d.forward)."""
+    tag = getattr(x, "_vdx_cfg_dup", None)
+    try:
+        return tag is not None and tag == x._version
+    except Exception:       # inference-mode tensors do not track versions
+        return False
 
 
 def cfg_ddim_step(eps2, lat, guidance, coeffs, out=None):

@@ -82,6 +82,7 @@ class UNet3DConditionModel(nn.Module):
         self.fuse_tconv = True         # K3 where it is faster — level 0 (False: GroupNorm apply pass + temporal-conv GEMM; "always": wherever the shape allows, tests)
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
+        self.share_cfg_prefix = True           # a CFG batch built by ops.cfg_input: the blocks before the first cross-attention run on ONE item (forward)
         self._text_ref = None                  # (encoder_hidden_states object, its version, (B, device), padded copy)
         self._text_kv: Dict[str, tuple] = {}   # cross-attention K / V^T of that text, per transformer
 
@@ -305,7 +306,7 @@ class UNet3DConditionModel(nn.Module):
     # ------------------------------------------------------------------------------------------
     # building blocks (all on row matrices)
     # ------------------------------------------------------------------------------------------
-    def _resnet(self, p, x, x2, temb_all, n_img, F, hh, ww):
+    def _resnet(self, p, x, x2, temb_all, n_img, F, hh, ww, part=0, ksplit_ok=True):
         """x may be a one- or two-element LIST [x] / [x, skip] the caller has handed over (its only references): the
         inputs are then released as soon as the shortcut and the first GroupNorm have consumed them — in the up path
         the block input AND the skip tensor, 2 x 189 MB at level 0 of a 16-frame chunk, before the convolutions
@@ -334,10 +335,11 @@ class UNet3DConditionModel(nn.Module):
             # the up blocks the [rows][C1 + C2] concat, the widest tensor of the block — is never written, so the memory-lean
             # pieces below have nothing to do either
             h = ops.conv3x3_gn(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], W[p + ".conv1.weight"], x2=x2, bias=W[p + ".conv1.bias"],
-                               bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, groups=g, n_img=n_img, h=hh, wd=ww, eps=eps)
+                               bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, groups=g, n_img=n_img, h=hh, wd=ww, eps=eps,
+                               partition_samples=part)
             del x, x2
             return ops.conv3x3_gn(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], W[p + ".conv2.weight"], bias=W[p + ".conv2.bias"],
-                                  residual=sc, groups=g, n_img=n_img, h=hh, wd=ww, eps=eps)
+                                  residual=sc, groups=g, n_img=n_img, h=hh, wd=ww, eps=eps, partition_samples=part)
         pieces = 0
         if self.ff_block_bytes and self.lean_concat and x2 is not None and M * cout * 2 > (64 << 20):
             # memory-lean mode, concat input (up path): the normalised concat [rows][C1 + C2] is the widest tensor of
@@ -355,7 +357,7 @@ class UNet3DConditionModel(nn.Module):
             for i in range(pieces):
                 r0 = i * pm
                 n1 = ops.groupnorm(x[r0:r0 + pm], W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=pn,
-                                   rows_per_sample=S, eps=eps, silu_act=True, x2=x2[r0:r0 + pm], partition_samples=n_img)
+                                   rows_per_sample=S, eps=eps, silu_act=True, x2=x2[r0:r0 + pm], partition_samples=part or n_img)
                 ops.gemm(n1, W[p + ".conv1.weight"], M=pm, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
                          bias2=temb_all[r0 // (F * S):, off:off + cout], rows_per_bias2=F * S,
                          conv=(pn, hh, ww, hh, ww, 1, False), out=h[r0:r0 + pm])
@@ -363,19 +365,19 @@ class UNet3DConditionModel(nn.Module):
             del x, x2
         else:
             h = ops.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups=g, n_samples=n_img,
-                              rows_per_sample=S, eps=eps, silu_act=True, x2=x2)
+                              rows_per_sample=S, eps=eps, silu_act=True, x2=x2, partition_samples=part)
             del x, x2
             # (split-K tail allowed unless this is a product the memory-lean order cuts into pieces: a piece and the
             # whole must keep the same summation order, the sharded forward has the bits of the resident one)
             h = ops.gemm(h, W[p + ".conv1.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv1.bias"],
                          bias2=temb_all[:, off:off + cout], rows_per_bias2=F * S, conv=geo,
-                         allow_ksplit=not (concat_in and M * cout * 2 > (64 << 20)))
+                         allow_ksplit=ksplit_ok and not (concat_in and M * cout * 2 > (64 << 20)))
         h = ops.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups=g, n_samples=n_img,
-                          rows_per_sample=S, eps=eps, silu_act=True)
+                          rows_per_sample=S, eps=eps, silu_act=True, partition_samples=part)
         return ops.gemm(h, W[p + ".conv2.weight"], M=M, mode=ops.CONV3X3, bias=W[p + ".conv2.bias"],
-                        residual=sc, conv=geo, allow_ksplit=True)
+                        residual=sc, conv=geo, allow_ksplit=ksplit_ok)
 
-    def _temp_conv(self, p, x, B, F, S):
+    def _temp_conv(self, p, x, B, F, S, part=0, ksplit_ok=True):
         W, g = self.W, self.cfg.norm_num_groups
         M = B * F * S
         y = x
@@ -386,18 +388,18 @@ class UNet3DConditionModel(nn.Module):
                 # K3: the GroupNorm apply + SiLU happen inside the convolution (statistics pass + one kernel; the
                 # normalised tensor is never written)
                 y = ops.tconv_gn(y, W[f"{p}.conv{i}.0.weight"], W[f"{p}.conv{i}.0.bias"], wi, bias=W[f"{p}.conv{i}.bias"],
-                                 residual=x if i == 4 else None, groups=g, B=B, F=F, S=S, eps=1e-5)
+                                 residual=x if i == 4 else None, groups=g, B=B, F=F, S=S, eps=1e-5, partition_samples=part)
                 continue
             n = ops.groupnorm(y, W[f"{p}.conv{i}.0.weight"], W[f"{p}.conv{i}.0.bias"], groups=g, n_samples=B,
-                              rows_per_sample=F * S, eps=1e-5, silu_act=True)
+                              rows_per_sample=F * S, eps=1e-5, silu_act=True, partition_samples=part)
             y = ops.gemm(n, W[f"{p}.conv{i}.weight"], M=M, mode=ops.TCONV3, bias=W[f"{p}.conv{i}.bias"],
-                         tconv=(F, S), residual=x if i == 4 else None, allow_ksplit=True)
+                         tconv=(F, S), residual=x if i == 4 else None, allow_ksplit=ksplit_ok)
         return y
 
     # Temporaries are released as soon as their consumer has been enqueued (`del`): kernels run in stream order,
     # so the caching allocator can hand the block to the next op.  Left to Python scoping, every intermediate of
     # a transformer block lived until the block returned: 5.6 GB of activations at the 24-frame peak instead of 3.
-    def _ff(self, b, t, M):
+    def _ff(self, b, t, M, ksplit_ok=True):
         W = self.W
         inner = t.shape[1]
         if self.fuse_ff and b + ".ff.k8" in W and ops.ff_block_supported(inner):
@@ -420,7 +422,7 @@ class UNet3DConditionModel(nn.Module):
             gg = ops.gemm(ln, W[b + ".ff.net.0.proj.weight"], M=M, bias=W[b + ".ff.net.0.proj.bias"], geglu=True)
             del ln
             return ops.gemm(gg, W[b + ".ff.net.2.weight"], M=M, bias=W[b + ".ff.net.2.bias"], residual=t,
-                            allow_ksplit=M * 8 * inner <= (256 << 20))      # (never a shape the lean order cuts into row blocks)
+                            allow_ksplit=ksplit_ok and M * 8 * inner <= (256 << 20))      # (never a shape the lean order cuts into row blocks)
         out = torch.empty_like(t[:M])
         for r0 in range(0, M, blk):
             r1 = min(r0 + blk, M)
@@ -432,28 +434,39 @@ class UNet3DConditionModel(nn.Module):
             del gg
         return out
 
-    def _norm_proj_in(self, p, x, n_samples, rows_per_sample, M):
+    def _norm_proj_in(self, p, x, n_samples, rows_per_sample, M, part=0):
         """`norm` -> `proj_in` at the entry of a transformer: GroupNorm (eps 1e-6, no activation) then a Linear.  Where the
         Linear runs on the weights-stationary kernels (levels 0 / 1, transformer_in) the norm is FOLDED into it — per-sample
         weights and an fp32 bias from the statistics, the GEMM reads the raw rows (ops.groupnorm_linear): the normalised
         tensor, one read and one write of the activation, never exists."""
         W, g = self.W, self.cfg.norm_num_groups
         w = W[p + ".proj_in.weight"]
-        if self.fold_norm_proj_in and M >= 16384 and M % 64 == 0 and ops.groupnorm_linear_supported(x.shape[1], w.shape[0], rows_per_sample):
+        # (`part`: the samples of the batch these rows stand for — the CFG-shared prefix normalises ONE item with the slab
+        # partition, and takes the fold, of the batch of two: its bits must not depend on how many items are computed)
+        m_sel = M * (part // n_samples) if part else M
+        if self.fold_norm_proj_in and m_sel >= 16384 and M % 64 == 0 and ops.groupnorm_linear_supported(x.shape[1], w.shape[0], rows_per_sample):
             return ops.groupnorm_linear(x, W[p + ".norm.weight"], W[p + ".norm.bias"], w, W[p + ".proj_in.bias"], groups=g,
-                                        n_samples=n_samples, rows_per_sample=rows_per_sample, eps=1e-6)
+                                        n_samples=n_samples, rows_per_sample=rows_per_sample, eps=1e-6, partition_samples=part)
         n = ops.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups=g, n_samples=n_samples,
-                          rows_per_sample=rows_per_sample, eps=1e-6, silu_act=False)
+                          rows_per_sample=rows_per_sample, eps=1e-6, silu_act=False, partition_samples=part)
         return ops.gemm(n, w, M=M, bias=W[p + ".proj_in.bias"])
 
-    def _spatial_transformer(self, p, x, ehs_pad, n_img, F, hh, ww):
+    def _spatial_transformer(self, p, x, ehs_pad, n_img, F, hh, ww, dup=False):
+        """`dup` (the first spatial transformer of a CFG batch whose two items are the same tensor, forward): x holds ONE
+        item's rows [n_img/2 * S][C].  `norm` -> `proj_in` -> self-attention -> + and the LayerNorm and query projection
+        of the cross-attention see no text, so they are computed once; the two items part at the cross-attention's keys /
+        values.  Returns the rows of both items."""
         W, g = self.W, self.cfg.norm_num_groups
-        S, M = hh * ww, n_img * hh * ww
+        S = hh * ww
+        M_out = n_img * S
+        if dup:
+            n_img //= 2
+        M = n_img * S
         C = x.shape[1]
         heads = C // 64
         scale = 64 ** -0.5
         b = p + ".transformer_blocks.0"
-        t = self._norm_proj_in(p, x, n_img, S, M)
+        t = self._norm_proj_in(p, x, n_img, S, M, part=2 * n_img if dup else 0)
         # --- self-attention: q | k | v from ONE projection; the flash kernel takes V as rows (transposed by its LDS read),
         # so there is no V^T product and no padded copy for token counts that are no multiple of 8 (latent 40x72 ->
         # 5x9 = 45 tokens at the mid block, InferNet/tests/test_pipeline.py:293; 16x16 -> 2x2 = 4, InferNet/neurons/miner.py:491-494)
@@ -499,6 +512,22 @@ class UNet3DConditionModel(nn.Module):
             self._text_kv[p] = (k, vt)
         else:
             k, vt = kv
+        if dup:
+            # one query tensor, the keys / values of each item in turn; the residual rows (and, at the block's end, the
+            # transformer's input rows) are the shared item's for both — two launches over half the rows each, no copy
+            t2 = torch.empty((M_out, C), dtype=torch.float16, device=x.device)
+            for i in range(nb):
+                o = ops.flash_attn(q, k[i * TEXT_PAD:(i + 1) * TEXT_PAD], vt[:, i * TEXT_PAD:(i + 1) * TEXT_PAD], n_seq=n_img, sq=S,
+                                   skv=self._text_len, skv_pad=TEXT_PAD, heads=heads, seq_per_kv=n_img, scale=scale)
+                ops.gemm(o, W[b + ".attn2.to_out.0.weight"], M=M, bias=W[b + ".attn2.to_out.0.bias"], residual=t, out=t2[i * M:(i + 1) * M])
+                del o
+            del q
+            t = self._ff(b, t2, M_out)
+            del t2
+            out = torch.empty((M_out, C), dtype=torch.float16, device=x.device)
+            for i in range(nb):
+                ops.gemm(t[i * M:(i + 1) * M], W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x, out=out[i * M:(i + 1) * M])
+            return out
         o = ops.flash_attn(q, k, vt, n_seq=n_img, sq=S, skv=self._text_len, skv_pad=TEXT_PAD, heads=heads,
                            seq_per_kv=n_img // nb, scale=scale)
         del q
@@ -507,12 +536,12 @@ class UNet3DConditionModel(nn.Module):
         t = self._ff(b, t, M)
         return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
 
-    def _temporal_transformer(self, p, x, B, F, S, heads):
+    def _temporal_transformer(self, p, x, B, F, S, heads, part=0, ksplit_ok=True):
         W, g = self.W, self.cfg.norm_num_groups
         M = B * F * S
         scale = 64 ** -0.5
         b = p + ".transformer_blocks.0"
-        t = self._norm_proj_in(p, x, B, F * S, M)
+        t = self._norm_proj_in(p, x, B, F * S, M, part=part)
         fused = self.fuse_temporal_attention and f"{b}.attn1.k7_qkv" in W and ops.temporal_attn_block_supported(t.shape[1], F)
         fused2 = self.fuse_temporal_attention and f"{b}.attn1.k7b" in W and ops.temporal_attn_block2_supported(t.shape[1], F)
         for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
@@ -530,7 +559,7 @@ class UNet3DConditionModel(nn.Module):
             del qkv
             t = ops.gemm(o, W[f"{b}.{a}.to_out.0.weight"], M=M, bias=W[f"{b}.{a}.to_out.0.bias"], residual=t)
             del o
-        t = self._ff(b, t, M)
+        t = self._ff(b, t, M, ksplit_ok=ksplit_ok)
         return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
 
     # ------------------------------------------------------------------------------------------
@@ -565,6 +594,7 @@ class UNet3DConditionModel(nn.Module):
         # upsampler then resizes to the resolution of the skip tensor it will meet)
         if F > 128:
             raise VdxError("temporal attention kernel handles at most 128 frames per chunk")
+        cfg_dup = ops.is_cfg_duplicate(sample)
         sample = sample.to(torch.float16).contiguous()
         ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16)
         if ehs.shape[0] != B or ehs.shape[2] != c.cross_attention_dim or ehs.shape[1] > TEXT_PAD:
@@ -598,16 +628,35 @@ class UNet3DConditionModel(nn.Module):
         temb_all = ops.gemm(ops.silu(e), W["time_emb_proj_all.weight"], M=B, bias=W["time_emb_proj_all.bias"])
 
         hh, ww = H, Wd
-        x = ops.conv_in(sample, W["conv_in.weight"], W["conv_in.bias"])
-        x = self._temporal_transformer("transformer_in", x, B, F, hh * ww, c.transformer_in_heads)
+        # The CFG-shared prefix.  `cat([lat]*2)` (+ the same context term, fsdp_chunked_coherent.py:133-137) makes the two
+        # items of the batch the SAME tensor, and nothing before the first cross-attention sees the text: conv_in,
+        # transformer_in, the first ResnetBlock / TemporalConvLayer and the first spatial transformer up to its
+        # cross-attention's keys would compute every row twice.  When the caller's tensor is known to be such a
+        # duplicate — it came out of `ops.cfg_input` and has not been written since (a tag, never a guess: comparing
+        # the halves would cost a sync) — those blocks run on ONE item (B1 = 1) with the statistics partition of the
+        # batch of two, and the rows fan out at the cross-attention.  Same kernels on the same rows in the same order:
+        # the output has the bits of the duplicated forward (tests/test_unet_gpu.py::test_cfg_shared_prefix_*).
+        # The blocks of the prefix never take the split-K tail in EITHER form (its plan depends on the row count).
+        dup = bool(self.share_cfg_prefix and B == 2 and cfg_dup and c.down_block_types[0].startswith("CrossAttn"))
+        self.last_forward_shared_prefix = dup
+        B1 = 1 if dup else B
+        part = B if dup else 0
+        x = ops.conv_in(sample[:B1], W["conv_in.weight"], W["conv_in.bias"])
+        x = self._temporal_transformer("transformer_in", x, B1, F, hh * ww, c.transformer_in_heads, part=part, ksplit_ok=False)
         skips = [(x, hh, ww)]
+        shared_skip = dup                       # skips[0] holds one item's rows; doubled where it is consumed (the last up ResNet)
         for i, t in enumerate(c.down_block_types):
             p = f"down_blocks.{i}"
             for j in range(c.layers_per_block):
-                x = self._resnet(f"{p}.resnets.{j}", x, None, temb_all, n_img, F, hh, ww)
-                x = self._temp_conv(f"{p}.temp_convs.{j}", x, B, F, hh * ww)
+                first = i == 0 and j == 0
+                if first:
+                    x = self._resnet(f"{p}.resnets.{j}", x, None, temb_all, B1 * F, F, hh, ww, part=part * F, ksplit_ok=False)
+                    x = self._temp_conv(f"{p}.temp_convs.{j}", x, B1, F, hh * ww, part=part, ksplit_ok=False)
+                else:
+                    x = self._resnet(f"{p}.resnets.{j}", x, None, temb_all, n_img, F, hh, ww)
+                    x = self._temp_conv(f"{p}.temp_convs.{j}", x, B, F, hh * ww)
                 if t.startswith("CrossAttn"):
-                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs_pad, n_img, F, hh, ww)
+                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs_pad, n_img, F, hh, ww, dup=dup and first)
                     x = self._temporal_transformer(f"{p}.temp_attentions.{j}", x, B, F, hh * ww, x.shape[1] // 64)
                 skips.append((x, hh, ww))
             if i != nlev - 1:
@@ -630,6 +679,8 @@ class UNet3DConditionModel(nn.Module):
                 skip, sh, sw = skips.pop()
                 if (sh, sw) != (hh, ww):
                     raise VdxError("skip connection resolution mismatch")
+                if shared_skip and not skips:
+                    skip = torch.cat([skip, skip])          # transformer_in's output stood for both items (one 2 x 141 MB copy at 24 frames)
                 owned = [x, skip]
                 x = skip = None
                 x = self._resnet(f"{p}.resnets.{j}", owned, None, temb_all, n_img, F, hh, ww)

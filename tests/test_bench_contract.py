@@ -83,3 +83,26 @@ def test_perf_guard_flags_a_slower_dominant_kernel(tmp_path):
     slow.write_text(hdr + row.format(k1, 105, 945000.0) + row.format(k2, 45, 2203000.0))
     r = subprocess.run([sys.executable, tool, str(slow), str(ref)], capture_output=True, text=True)
     assert r.returncode == 0 and "box factor" in r.stdout, r.stdout
+
+
+def test_bare_bench_gpus_n_launches_itself(tmp_path):
+    """`python bench.py --gpus N` with no launcher: the parent re-runs itself under torch.distributed.run
+    and relays the outcome.  Without a GPU the ranks die in `torch.cuda.set_device`; what is checked here is that they were
+    started as N ranks (each names its rank), that the parent's exit code is the launcher's, and that no JSON line is
+    invented.  (The two-rank run that completes is the -m gpu test `test_bench_self_launch_two_ranks_on_one_gpu`.)"""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.self_launch_command(["--gpus", "2", "--steps", "1"], 2, 29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "1"]
+    assert cmd[cmd.index("29999") + 1] == os.path.join(ROOT, "bench.py")
+    import torch
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr or "rank: 1" in r.stderr, r.stderr[-2000:]
