@@ -35,6 +35,7 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "vdx_last_error": (C.c_char_p, []),
     "vdx_version": (_i, []),
+    "vdx_build_flags": (_i, []),
     "vdx_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
     "vdx_gemm_plan": (_i, [C.POINTER(GemmArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vdx_gemm_plan_ksplit": (_i, [C.POINTER(GemmArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
@@ -122,6 +123,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    flags = lib.vdx_build_flags()
+    if flags and os.environ.get("VDX_ALLOW_LAB_BUILD") != "1":
+        # VDX_LIB_PATH must not slip a stamps / ablation build (timing-only code paths, some with wrong results) into the product
+        raise VdxError(f"{LIB_PATH} was built with lab macros (vdx_build_flags() = {flags}): not a parity build. "
+                       "Lab tools set VDX_ALLOW_LAB_BUILD=1; the product path never does.")
     _lib = lib
     return lib
 

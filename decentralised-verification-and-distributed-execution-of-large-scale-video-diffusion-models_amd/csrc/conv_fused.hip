@@ -371,3 +371,14 @@ extern "C" int vdx_conv3x3_gn_f16(const void* a, int lda, const void* a2, int ld
     hipLaunchKernelGGL(conv3x3_gn_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p);
     return vdx_launch_status("vdx_conv3x3_gn_f16");
 }
+
+// Lab variants of this translation unit (phase stamps, ablations: timing only, some give WRONG results) are compiled in only
+// under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
+// as the product.
+extern "C" int vdx_lab_conv_fused(void) {
+#if defined(K1_ABL_NOPIN) || defined(K1_ABL_NONORM)
+    return 64;
+#else
+    return 0;
+#endif
+}

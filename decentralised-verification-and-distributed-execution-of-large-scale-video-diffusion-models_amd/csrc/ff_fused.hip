@@ -516,3 +516,14 @@ extern "C" int vdx_ff_block_f16(const void* t, int ldt, const void* packed, floa
     hipLaunchKernelGGL(ff_fused_kernel<320>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return vdx_launch_status("vdx_ff_block_f16");
 }
+
+// Lab variants of this translation unit (phase stamps, ablations: timing only, some give WRONG results) are compiled in only
+// under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
+// as the product.
+extern "C" int vdx_lab_ff_fused(void) {
+#if defined(K8_ABL_NOSEAM) || defined(K8_ABL_NOWDMA) || defined(K8_ABL_NOLDSX) || defined(K8_ABL_NOLDSW) || defined(K8_ABL_NOGEGLU) || defined(K8_ABL_NOBAR)
+    return 32;
+#else
+    return 0;
+#endif
+}

@@ -517,3 +517,14 @@ extern "C" int vdx_flash_stamps_read(void* host, size_t bytes) {
     return e == hipSuccess ? 0 : vdx_fail("flash_stamps_read: %s", hipGetErrorString(e));
 }
 #endif
+
+// Lab variants of this translation unit (phase stamps, ablations: timing only, some give WRONG results) are compiled in only
+// under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
+// as the product.
+extern "C" int vdx_lab_flash(void) {
+#if defined(FL_STAMPS) || defined(FL_ABL_NOEXP) || defined(FL_ABL_MFMA16) || defined(FL_ABL_NOVREAD) || defined(FL_ABL_NOSUM) || defined(FL_ABL_NOMAX) || defined(FL_ABL_NOKREAD) || defined(FL_ABL_NODMA) || defined(FL_ABL_NOBAR)
+    return 16;
+#else
+    return 0;
+#endif
+}

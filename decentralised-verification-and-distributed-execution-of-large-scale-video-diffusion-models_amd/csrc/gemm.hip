@@ -689,3 +689,14 @@ extern "C" int vdx_gemm_plan_ksplit(const vdx_gemm_args* a, int32_t* split_row, 
     *workspace_bytes = (size_t)t * S * KSPLIT_SLAB_BYTES;
     return 0;
 }
+
+// Lab variants of this translation unit (phase stamps, ablations: timing only, some give WRONG results) are compiled in only
+// under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
+// as the product.
+extern "C" int vdx_lab_gemm(void) {
+#if defined(VDX_STAMPS) || (defined(VDX_ABL) && VDX_ABL) || defined(VDX_GEMM_PLAIN_LOOP)
+    return 1;
+#else
+    return 0;
+#endif
+}

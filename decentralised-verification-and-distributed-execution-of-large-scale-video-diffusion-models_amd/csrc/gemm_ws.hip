@@ -364,3 +364,14 @@ int vdx_gemm_ws_launch(const GemmP& p, int family, bool geglu, hipStream_t st) {
     }
     return vdx_fail("gemm_ws: shape not supported");
 }
+
+// Lab variants of this translation unit (phase stamps, ablations: timing only, some give WRONG results) are compiled in only
+// under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
+// as the product.
+extern "C" int vdx_lab_gemm_ws(void) {
+#if defined(VDX_STAMPS)
+    return 2;
+#else
+    return 0;
+#endif
+}

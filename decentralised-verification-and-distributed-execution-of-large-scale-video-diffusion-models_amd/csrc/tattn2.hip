@@ -837,3 +837,14 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return vdx_launch_status("vdx_temporal_attn_block2_f16");
 }
+
+// Lab variants of this translation unit (phase stamps, ablations: timing only, some give WRONG results) are compiled in only
+// under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
+// as the product.
+extern "C" int vdx_lab_tattn2(void) {
+#if defined(K7B_STAMPS) || defined(K7B_ABL_NOROWS) || defined(K7B_ABL_NOEPI) || defined(K7B_ABL_NOATT) || defined(K7B_ABL_NOWDMA)
+    return 8;
+#else
+    return 0;
+#endif
+}

@@ -615,3 +615,14 @@ extern "C" int vdx_temporal_attn_block_f16(const void* t, int ldt, const void* g
     if (inner == 320) return launch_k7<320, 4, 1>(p, st);
     return launch_k7<512, 2, 2>(p, st);
 }
+
+// Lab variants of this translation unit (phase stamps, ablations: timing only, some give WRONG results) are compiled in only
+// under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
+// as the product.
+extern "C" int vdx_lab_tattn_fused(void) {
+#if defined(VDX_STAMPS) || defined(K7_ABL_NOP0) || defined(K7_ABL_NOMFMA) || defined(K7_ABL_NOEPI) || defined(K7_ABL_NODMA) || defined(K7_ABL_NOATT)
+    return 4;
+#else
+    return 0;
+#endif
+}

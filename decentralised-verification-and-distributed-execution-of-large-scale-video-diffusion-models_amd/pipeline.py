@@ -16,9 +16,10 @@ context_weight.  Differences in mechanism (results identical):
     accumulation order is the reference's (`for lst in gathered: for s,e,latc in lst`, :208-216), so the owned frames
     carry exactly the bits of the reference's full blend.
     `info["network_bytes"]` = bytes this rank RECEIVES in the exchange (allgather: (world-1) fixed-shape chunk lists;
-    halo: the halo frames).  The reference's CSV column of the same name is `payload_bytes` (:191), the bytes a rank
-    SENDS into `all_gather_object` (its own chunk list): both modes report that one as `info["payload_bytes"]`, and
-    a caller that writes the reference's CSV row (`metrics.csv_row`) passes it as the `network_bytes` column;
+    halo: the halo frames).  The reference's CSV column of the same name is `payload_bytes` (:194): frames x channels x 2
+    of the rank's own chunk list (the formula leaves the h x w extent out; kept, it is what the reference's rows hold):
+    both modes report that one as `info["payload_bytes"]` (and the real byte count as `payload_bytes_actual`), and
+    a caller that writes the reference's CSV row (`metrics.append_csv`) passes it as the `network_bytes` column;
   * the linear-ramp blend (:204-217) runs on the device, in the reference's accumulation order.
 """
 from __future__ import annotations
@@ -383,7 +384,8 @@ class DistributedVideoDiffuser:
             self._sync()
             info["net_gather_s"] = time.time() - t0
             info["network_bytes"] = (self.world - 1) * cp.per_rank * C * cp.chunk * H * W * 2    # received per rank
-            info["payload_bytes"] = sum(t.numel() * 2 for t in mine)                             # the reference's :191
+            info["payload_bytes"] = sum(t.shape[2] * C * 2 for t in mine)          # the reference's formula (:194), see below
+            info["payload_bytes_actual"] = sum(t.numel() * 2 for t in mine)
             return self.blend(chunks, base, cp.overlap), info
         if exchange != "halo":
             raise ValueError(f"unknown exchange {exchange!r}")
@@ -393,6 +395,10 @@ class DistributedVideoDiffuser:
         self._sync()
         info["net_gather_s"] = time.time() - t0
         info["network_bytes"] = sum(t.numel() * 2 for t in got.values())
-        info["payload_bytes"] = sum(t.numel() * 2 for t in mine)                                 # the reference's :191
+        # `payload_bytes = sum((e-s) * in_channels * 2 ...)` (:194) — frames x channels x 2 bytes WITHOUT the h x w extent: the
+        # value the reference's CSV column `network_bytes` carries (its executed rows: tests/golden/ref_exec_planner.json);
+        # the bytes a rank's chunk list really has are `payload_bytes_actual`
+        info["payload_bytes"] = sum(t.shape[2] * C * 2 for t in mine)
+        info["payload_bytes_actual"] = sum(t.numel() * 2 for t in mine)
         info["owned"] = [(s, e) for s, e, _ in owned]
         return owned, info

@@ -32,6 +32,10 @@ typedef void* vdx_stream_t;
 
 const char* vdx_last_error(void);
 int vdx_version(void);
+/* 0 for the product build.  Non-zero: some translation unit was compiled with a lab macro (phase stamps, ablations — timing
+ * only, some variants compute wrong results); bit = unit (1 gemm, 2 gemm_ws, 4 tattn_fused, 8 tattn2, 16 flash, 32 ff_fused,
+ * 64 conv_fused).  The Python binding refuses such a library unless VDX_ALLOW_LAB_BUILD=1 (the lab tools set it). */
+int vdx_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM family:  out[M][N] = epilogue( A_gathered[M][K] * W[N][K]^T )

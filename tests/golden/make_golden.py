@@ -184,6 +184,145 @@ def cfg1_main():
     np.savez_compressed(os.path.join(HERE, "cfg1_xl.npz"), lat=lat.numpy(), cs=cs, ov=ov, ranges=np.array(ranges))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Full-schedule trajectories: error growth over a whole DDIM schedule, not over one forward
+# ---------------------------------------------------------------------------------------------------------------
+def round_leaf_outputs_to_fp16(model):
+    """fp16-STORAGE emulation at fp32 speed: the output of every leaf module (convolution, Linear, GroupNorm, LayerNorm, ...)
+    is rounded to fp16 and widened again, sums inside a module stay fp32 — what a GPU fp16 pipeline does between kernels.
+    (The real fp16-CPU model is used where it finishes in minutes — tiny widths; torch's fp16 CPU kernels at the XL widths
+    would take hours.)  Returns the hook handles."""
+    def hook(_m, _inp, out):
+        return out.half().float() if torch.is_tensor(out) and out.dtype == torch.float32 else out
+    return [m.register_forward_hook(hook) for m in model.modules() if not list(m.children())]
+
+
+class Trajectory(FP32UNetOnHalfIO):
+    """Records the latent the loop feeds in at every step (x[:1] of the CFG batch, before the ctx term: ctx is None here or
+    the caller subtracts nothing — only used with ctx-free modes or via `lat_log`)."""
+    def __init__(self, m):
+        super().__init__(m)
+        self.eps_log = []
+
+    def forward(self, x, t, encoder_hidden_states):
+        o = super().forward(x, t, encoder_hidden_states)
+        self.eps_log.append(o.sample.clone())
+        return o
+
+
+def denoise_logged(unet, sched, lat, uncond, cond, gs=7.5, ctx=None, cw=0.35):
+    """`oracle.pipeline_ref.denoise` with the latent after every step kept (same statements, same order)."""
+    log = []
+    for t in sched.timesteps:
+        x = sched.scale_model_input(torch.cat([lat] * 2), t)
+        if ctx is not None:
+            x = x + cw * ctx.repeat(1, 1, lat.shape[2], 1, 1)
+        emb = torch.cat([uncond, cond], dim=0)
+        with torch.no_grad():
+            noise = unet(x, t, encoder_hidden_states=emb).sample
+        u, c = noise.chunk(2)
+        lat = sched.step(u + gs * (c - u), t, lat).prev_sample
+        log.append(lat.clone())
+    return lat, log
+
+
+CFG1_FULL = dict(T=8, H=32, W=32, steps=10)     # BASELINE config 1 at the real widths, ALL 10 DDIM steps
+
+
+def cfg1_full_main():
+    """BASELINE config 1 with its whole schedule: Zeroscope-XL widths, 8 frames @ 256x256 (32x32 latent), chunk_only planner
+    (windows (0,8),(6,8), ov 2), 10 DDIM steps per window, gather, ramp blend.  Two trajectories: the fp32 oracle (stored:
+    the latent of window (0,8) after EVERY step, fp16; the blended latent, fp32) and the fp16-storage emulation of the same
+    loop (stored: its rel-L2 distance to the fp32 trajectory after every step — the noise floor the HIP path is held to)."""
+    from oracle.pipeline_ref import base_noise, plan_chunks, ramp_blend
+    torch.set_num_threads(8)
+    cfg = UNet3DConfig.zeroscope()
+    sd = {k: v.half().float() for k, v in synthetic_state_dict(cfg, seed=1234).items()}
+    m = UNet3DConditionModelRef(cfg).eval()
+    m.load_state_dict(sd)
+    del sd
+    c = CFG1_FULL
+    uncond, cond = cfg1_embeddings()
+    cs, ov, ranges = plan_chunks(c["T"], 1, 0, 4, False, "third")
+    base = base_noise(c["T"], 4, c["H"], c["W"])
+    out = {"cs": cs, "ov": ov, "ranges": np.array(ranges)}
+    finals = {}
+    for tag in ("fp32", "fp16emu"):
+        hooks = round_leaf_outputs_to_fp16(m) if tag == "fp16emu" else []
+        u = FP32UNetOnHalfIO(m)
+        chunks = []
+        for s, e in ranges:
+            sched = DDIMSchedulerRef()
+            sched.set_timesteps(c["steps"])
+            lat, log = denoise_logged(u, sched, base[:, :, s:e].clone(), uncond, cond)
+            chunks.append((s, e, lat))
+            finals[(tag, s, e)] = log
+            print(f"cfg1_full {tag} window ({s},{e}): lat std {float(lat.float().std()):.4f}", flush=True)
+        finals[(tag, "blend")] = ramp_blend(chunks, c["T"], ov, base)
+        for h in hooks:
+            h.remove()
+    s0, e0 = ranges[0]
+    ref_log, emu_log = finals[("fp32", s0, e0)], finals[("fp16emu", s0, e0)]
+    out["lat_steps_w0"] = torch.stack([x[0] for x in ref_log]).numpy()                      # (steps, 4, 8, 32, 32) fp16
+    out["floor_steps_w0"] = np.array([rel_l2(a.float(), b.float()) for a, b in zip(emu_log, ref_log)])
+    out["lat"] = finals[("fp32", "blend")].numpy()
+    out["floor_blend"] = np.float64(rel_l2(finals[("fp16emu", "blend")], finals[("fp32", "blend")]))
+    print("cfg1_full: per-step fp16-emulation floor", np.array2string(out["floor_steps_w0"], precision=2), "blend", out["floor_blend"])
+    np.savez_compressed(os.path.join(HERE, "cfg1_xl_full.npz"), **out)
+
+
+SCHED50 = dict(T=12, H=16, W=16, steps=50, chunk=6, ov=2, every=5)
+
+
+def sched50_main():
+    """The reference's DEFAULT schedule length (50 steps, fsdp_chunked_coherent.py:284) on a `hybrid_ctx` job at tiny widths:
+    12 frames of a 16x16 latent, windows of 6 / overlap 2, global-context injection.  fp32 oracle trajectory (stored: window
+    0's latent after every 5th step and the blended latent) and the REAL fp16-CPU model's trajectory (stored: its rel-L2
+    distance to the fp32 one at the same steps)."""
+    from oracle.pipeline_ref import base_noise, global_context, plan_chunks, ramp_blend
+    torch.set_num_threads(8)
+    cfg = UNet3DConfig.tiny(**TINY)
+    sd16 = {k: v.half() for k, v in synthetic_state_dict(cfg, seed=1234).items()}
+    m32 = UNet3DConditionModelRef(cfg).eval()
+    m32.load_state_dict({k: v.float() for k, v in sd16.items()})
+    m16 = UNet3DConditionModelRef(cfg).eval().half()
+    m16.load_state_dict(sd16)
+
+    class Half(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m, self.config = m, m.config
+
+        def forward(self, x, t, encoder_hidden_states):
+            return self.m(x, t, encoder_hidden_states)
+
+    c = SCHED50
+    g = torch.Generator().manual_seed(1)
+    emb = torch.randn(2, 77, TINY["cross"], generator=g).half()
+    cond, uncond = emb[:1], emb[1:]
+    cs, ov, ranges = plan_chunks(c["T"], 1, c["chunk"], c["ov"], False, "coherent")
+    base = base_noise(c["T"], 4, c["H"], c["W"])
+    ctx = global_context(c["T"], 4, c["H"], c["W"])
+    res = {}
+    for tag, u in (("fp32", FP32UNetOnHalfIO(m32)), ("fp16", Half(m16))):
+        chunks = []
+        for s, e in ranges:
+            sched = DDIMSchedulerRef()
+            sched.set_timesteps(c["steps"])
+            lat, log = denoise_logged(u, sched, base[:, :, s:e].clone(), uncond, cond, 7.5, ctx, 0.35)
+            chunks.append((s, e, lat))
+            res[(tag, s, e)] = log
+        res[(tag, "blend")] = ramp_blend(chunks, c["T"], ov, base)
+    s0, e0 = ranges[0]
+    idx = list(range(c["every"] - 1, c["steps"], c["every"]))
+    out = {"cs": cs, "ov": ov, "ranges": np.array(ranges), "snap_steps": np.array(idx),
+           "lat_snaps_w0": torch.stack([res[("fp32", s0, e0)][i][0] for i in idx]).numpy(),
+           "floor_snaps_w0": np.array([rel_l2(res[("fp16", s0, e0)][i].float(), res[("fp32", s0, e0)][i].float()) for i in idx]),
+           "lat": res[("fp32", "blend")].numpy(), "floor_blend": np.float64(rel_l2(res[("fp16", "blend")], res[("fp32", "blend")]))}
+    print("sched50:", cs, ov, ranges, "fp16-CPU floor at steps", idx, np.array2string(out["floor_snaps_w0"], precision=2), "blend", out["floor_blend"])
+    np.savez_compressed(os.path.join(HERE, "sched50_tiny.npz"), **out)
+
+
 def vae_main():
     """AutoencoderKL decode (tiny widths, same topology): fp32 oracle output of seeded latents + the fp16-CPU
     noise floor of the same computation."""
@@ -246,6 +385,10 @@ if __name__ == "__main__":
         unet_xl_chunks_main()
     if what in ("cfg1", "all"):
         cfg1_main()
+    if what in ("cfg1_full", "all"):
+        cfg1_full_main()
+    if what in ("sched50", "all"):
+        sched50_main()
     if what in ("vae", "all"):
         vae_main()
     if what in ("clip", "all"):

@@ -380,3 +380,29 @@ def test_k8_counted_waits_match_the_emitted_isa(tmp_path):
                    check=True, timeout=600)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k8_check_waits.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_lab_build_is_refused_as_the_product(tmp_path):
+    """`VDX_LIB_PATH` must not slip a stamps / ablation library (timing-only code paths, some with wrong
+    results) into the product.  A library whose conv_fused unit is compiled with -DK1_ABL_NONORM reports it through
+    `vdx_build_flags()`; `_lib.load()` raises unless VDX_ALLOW_LAB_BUILD=1 (what the lab tools set)."""
+    import glob
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "decentralised-verification-and-distributed-execution-of-large-scale-video-diffusion-models_amd", "csrc")
+    objs = [o for o in glob.glob(os.path.join(csrc, "build", "*.o")) if os.path.basename(o) != "conv_fused.o"]
+    if len(objs) < 10:
+        pytest.skip("object files of the product build are not here (built elsewhere)")
+    lab_o, lab_so = str(tmp_path / "conv_fused_lab.o"), str(tmp_path / "libvdx_hip_lab.so")
+    hipcc = "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-DK1_ABL_NONORM", "-c",
+                    os.path.join(csrc, "conv_fused.hip"), "-o", lab_o], check=True, capture_output=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", lab_o] + objs + ["-ldl", "-o", lab_so], check=True, capture_output=True)
+    code = "import sys; sys.path.insert(0, %r); import vdx; from vdx import _lib; l = _lib.load(); print('flags', l.vdx_build_flags())" % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "VDX_ALLOW_LAB_BUILD"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, VDX_LIB_PATH=lab_so))
+    assert r.returncode != 0 and "lab macros" in r.stderr and "= 64" in r.stderr, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, VDX_LIB_PATH=lab_so, VDX_ALLOW_LAB_BUILD="1"))
+    assert r.returncode == 0 and "flags 64" in r.stdout, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "flags 0" in r.stdout, r.stderr[-1500:]

@@ -5,6 +5,7 @@ epilogue stores drained, s_memrealtime at both ends, HW_ID) and prints per-phase
 idle gap between consecutive blocks on the same CU."""
 import ctypes
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

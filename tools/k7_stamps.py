@@ -4,6 +4,7 @@ of each block): P0 load+LayerNorm, P1 wait/barrier/DMA-issue, P1 LDS reads + MFM
 P3 epilogue.  Shares only — the stamps forbid overlaps the product kernel has."""
 import ctypes
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """Dev tool: wall time of the fused temporal-attention kernel alone (library from VDX_LIB_PATH), level-0 and
 transformer_in shapes, median of 9."""
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 import torch

@@ -2,6 +2,7 @@
 """Dev tool: one small launch of the second fused temporal-attention kernel (csrc/tattn2.hip) against fp32, with the
 error broken down by row tile / column group so that an indexing fault shows its shape.  Library from VDX_LIB_PATH."""
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 import torch

@@ -3,6 +3,7 @@
 (hipcc -DK7B_STAMPS csrc/tattn2.hip -> libvdx_hip_k7bstamps.so; shares only, the stamps cost time)."""
 import ctypes as C
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 import numpy as np

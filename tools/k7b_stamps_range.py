@@ -2,6 +2,7 @@
 """Dev tool: cycles of one range of steps of csrc/tattn2.hip from a -DK7B_STAMPS -DK7B_SS=a -DK7B_SE=b build (VDX_LIB_PATH)."""
 import ctypes as C
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """Dev tool: wall time of the second fused temporal-attention kernel alone (library from VDX_LIB_PATH: the product or a
 -DK7B_ABL_* timing-only build), level-0 shape, F = 24 and 16, median of 9."""
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 import torch

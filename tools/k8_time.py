@@ -2,6 +2,7 @@
 """Dev tool: wall time of the fused feed-forward kernel alone (library from VDX_LIB_PATH: the product or a -DK8_ABL_*
 timing-only build made by tools/k8_abl.sh), level-0 shape, F = 24 and 16, median of 9."""
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 import torch

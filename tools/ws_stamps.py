@@ -3,6 +3,7 @@
 barrier wait, DMA issue, and everything between two chunk barriers (LDS reads + MFMA + epilogue + vmcnt wait)."""
 import ctypes
 import os
+os.environ.setdefault("VDX_ALLOW_LAB_BUILD", "1")      # lab tool: may load a stamps / ablation build
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
