@@ -183,7 +183,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal aid: every rank computes on cuda:0")
     ap.add_argument("--native-comm", action="store_true",
                     help="distributed / rehearsal runs: gather the parameter shards through the C-ABI RCCL entry point "
-                         "(vdx_allgather_shard, vdx/comm.py) instead of the default peer-mapped copies")
+                         "(vdx_allgather_shard, vdx/comm.py) instead of torch.distributed's all_gather_into_tensor")
+    ap.add_argument("--shard-transport", default=None, choices=["collective", "peer"],
+                    help="parameter-gather transport of the shard store (default: collective = RCCL all-gather; peer = HIP-IPC mapped "
+                         "arenas + copy-engine pulls, opt-in: vdx/shard.py)")
     ap.add_argument("--rehearsal", action="store_true",
                     help="required with --backend gloo / --share-gpu / --frames / --resident: states that the line is a "
                          "rehearsal, not a measurement of the BASELINE configuration (a driver run cannot take one by accident)")
@@ -261,7 +264,7 @@ def main():
         if args.native_comm:
             from vdx.comm import Comm
             comm = Comm.from_torch(dev)
-        unet.shard_(rank, world, comm=comm)       # 1/N of every unit per GPU, gathered per unit on a side stream
+        unet.shard_(rank, world, comm=comm, transport=args.shard_transport)       # 1/N of every unit per GPU, gathered per unit on a side stream
         if args.rehearse_dist and args.rehearse_copies and args.as_world > 1 and world == 1:
             # a gather = as_world LOCAL copies: the host-side call count of a node.  (On one GPU every one of them is a
             # blit kernel on the GPU that is computing; on a node 7 of 8 are remote pulls.  An upper bound of the cost.)

@@ -9,12 +9,18 @@ after the compute stream has passed the unit that used it.  Inference only: no r
 Sharding changes memory, never results.
 
 Transports of the gather (`transport=`, env VDX_SHARD_TRANSPORT):
-  "peer"        (default on GPUs) the ranks' shard arenas are mapped into each other once (HIP IPC, `vdx_ipc_*`);
-                a gather is `world` device-to-device copies on the side stream (`vdx_peer_gather`): copy engines over
-                xGMI, NO compute unit taken from the GEMMs that run meanwhile, and no collective at all — parameters
-                are read-only after load, so a rank pulls what it needs when it needs it (SURVEY §5.8);
-  "collective"  `torch.distributed.all_gather_into_tensor` (backend "nccl" = RCCL: gather KERNELS on the side stream),
-                or `all_gather` over gloo (CPU tensors, tests); the fallback when the peer mapping cannot be set up;
+  "collective"  (DEFAULT, round 5) `torch.distributed.all_gather_into_tensor` on the side stream — backend "nccl" = RCCL
+                over xGMI, what the north star names — or `all_gather` over gloo (CPU tensors, tests);
+  "peer"        (opt-in) the ranks' shard arenas are mapped into each other once (HIP IPC, `vdx_ipc_*`); a gather is
+                `world` device-to-device copies on the side stream (`vdx_peer_gather`): copy engines over xGMI, no compute
+                unit taken from the GEMMs that run meanwhile, no collective — parameters are read-only after load, so a
+                rank pulls what it needs when it needs it.  It was the default through round 4.  Round 5
+                ran it for the first time between two processes at FULL size (1.3 GB arenas, both ranks on the one GPU
+                of a box): the mapping opened but its self-check against the collective FAILED (the store fell back, as
+                designed), and a stand-alone probe of `hipIpcOpenMemHandle` on an arena of that size did not return
+                (profiles/r05_peer_transport.md).  Both ranks sat on one device there, which a node never has, but no node
+                was available to show the cross-device case works either — so the only multi-GPU run this build may
+                get goes through RCCL, and the peer transport stays available for whoever can measure it;
   comm=         the C-ABI RCCL entry point `vdx_allgather_shard` (vdx/comm.py).
 
 The store is a read-only mapping (name -> tensor view) and is what `UNet3DConditionModel.W`
@@ -76,8 +82,8 @@ class ShardedStore:
                  merge_bytes: int = 64 << 20):
         """`unit_of(name)` -> unit id, or None for tensors kept replicated (small stem tensors).
         `comm`: a `vdx.comm.Comm` — the gathers then go through the C-ABI (`vdx_allgather_shard`, RCCL) instead of
-        `torch.distributed`.  `transport`: "peer" | "collective" (module docstring); default from VDX_SHARD_TRANSPORT,
-        else "peer" on GPUs.  `merge_bytes`: neighbours of the schedule are gathered TOGETHER while their sum stays within
+        `torch.distributed`.  `transport`: "collective" | "peer" (module docstring); default from VDX_SHARD_TRANSPORT,
+        else "collective".  `merge_bytes`: neighbours of the schedule are gathered TOGETHER while their sum stays within
         this many bytes (fewer, larger transfers: the level-0 / level-1 units of the XL UNet are 2-18 MB each and a gather
         is `world` copies or one collective whatever its size); the two gather buffers are sized by the largest unit
         anyway (95 MB), so merging below that costs no memory.  0 = one gather per unit."""
@@ -137,7 +143,7 @@ class ShardedStore:
         self.gather_host_s = 0.0               # host time spent ENQUEUEING gathers (perf_counter around the transport call)
         self._peer_ptrs = None
         self._opened: List = []                # (peer pid, handle) of every mapping this store holds a reference to
-        want = transport or os.environ.get("VDX_SHARD_TRANSPORT") or ("peer" if self._cuda else "collective")
+        want = transport or os.environ.get("VDX_SHARD_TRANSPORT") or "collective"
         if want not in ("peer", "collective"):
             raise ValueError(f"unknown shard transport {want!r}")
         if want == "peer" and self._cuda and comm is None and (world > 1 or _FORCE_COLLECTIVE() or transport == "peer"):
@@ -217,7 +223,10 @@ class ShardedStore:
         self._opened, self._peer_ptrs, self.transport = [], None, "collective"
 
     def close(self):
-        """Release the peer mappings (idempotent).  The store stays usable: gathers then go through the collective."""
+        """Release the peer mappings (idempotent).  A COLLECTIVE call for a world > 1: every rank of the group must call it
+        at the same point of the program — afterwards the gathers go through the collective, and a rank that switched alone
+        would wait in its next all-gather for peers that still pull through their mappings.  Garbage
+        collection of a store (`__del__`) on one rank only is safe only when that rank gathers no more."""
         self._close_peer()
 
     def __del__(self):

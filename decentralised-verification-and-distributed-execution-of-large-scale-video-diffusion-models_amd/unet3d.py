@@ -292,8 +292,8 @@ class UNet3DConditionModel(nn.Module):
 
     def shard_(self, rank: int, world: int, group=None, comm=None, transport=None, merge_bytes: int = 64 << 20):
         """Keep 1/world of every unit on this GPU; gather per unit with prefetch (vdx/shard.py).  `comm`: gather through
-        the C-ABI RCCL entry point instead of torch.distributed (vdx/comm.py); `transport`: "peer" (mapped shard arenas,
-        copy-engine pulls: the default on GPUs) or "collective"."""
+        the C-ABI RCCL entry point instead of torch.distributed (vdx/comm.py); `transport`: "collective" (RCCL all-gather on the
+        side stream: the default) or "peer" (mapped shard arenas, copy-engine pulls: opt-in, vdx/shard.py)."""
         from .shard import ShardedStore
         if not isinstance(self.W, dict):
             raise VdxError("weights are already sharded")

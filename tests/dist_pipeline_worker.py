@@ -37,7 +37,7 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     m, emb = build(dev, rank, world)
-    want_transport = os.environ.get("VDX_SHARD_TRANSPORT", "peer")
+    want_transport = os.environ.get("VDX_SHARD_TRANSPORT", "collective")
     if world > 1:
         assert m.W.transport == want_transport, (m.W.transport, want_transport)
     cfg = DiffuserConfig(num_frames=T, steps=steps, chunk_size=chunk, overlap=ov, height=256, width=256, mode=mode,

@@ -36,6 +36,14 @@ def load(d):
     return per, dur, n
 
 
+def in_step(kernel: str) -> bool:
+    """Is this one of the build's own kernels (what a denoising step launches)?  Everything torch launches while the
+    profiled process synthesises its weights and inputs — `at::native::*` fills / copies / RNG, runtime blit kernels, any
+    library GEMM — is outside a step and must not be summed into the step's HBM traffic (it was, +5 %)."""
+    return not (kernel.startswith("at::native") or kernel.startswith("at::") or "__amd_rocclr_" in kernel or
+                kernel.startswith("rocblas") or kernel.startswith("Cijk_") or kernel.startswith("void at::"))
+
+
 def main():
     merged = collections.defaultdict(dict)
     durs, counts = {}, {}
@@ -81,7 +89,9 @@ def main():
         # identity of what was profiled: bench.py reports `roofline.traffic` from this file only when the kernel
         # sources it runs hash to the same value (a stale profile gives traffic = null, not a wrong number)
         out["_meta"] = {"source_sha": source_sha(), "forwards": forwards,
-                        "hbm_bytes_all_kernels": sum(rd + wr for t, k, n, rd, wr, bw, util in rows),
+                        # the build's own kernels only: what the `forwards` UNet forwards of the profiled command moved
+                        "hbm_bytes_all_kernels": sum(rd + wr for t, k, n, rd, wr, bw, util in rows if in_step(k)),
+                        "hbm_bytes_outside_the_step": sum(rd + wr for t, k, n, rd, wr, bw, util in rows if not in_step(k)),
                         "kernels": sorted(k for t, k, n, rd, wr, bw, util in rows if n)}
         json.dump(out, open(json_out, "w"), indent=1)
     print("| kernel | launches | time share | HBM read GB (x2-corrected) | HBM write GB | HBM GB/s | MFMA busy |")
