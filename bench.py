@@ -195,6 +195,8 @@ def main():
                          "nats above the mean, as trained checkpoints have) — the lazy softmax offset of the flash kernel then "
                          "has to move; the default synthetic weights give near-uniform attention, its best case")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-shared-prefix", action="store_true",
+                    help="diagnostic (needs --rehearsal): every block computes both CFG items, as a forward on torch.cat([lat]*2) does")
     ap.add_argument("--no-duplicate-leg", action="store_true",
                     help="skip the second timing of the same steps with the CFG-shared prefix off (`ms_per_step_full_duplicate`)")
     ap.add_argument("--rehearse-copies", action="store_true",
@@ -211,7 +213,8 @@ def main():
     ap.add_argument("--resident", action="store_true",
                     help="diagnostic: keep the UNet weights resident (no shard store) in a distributed / rehearsal run")
     args = ap.parse_args()
-    if (args.backend != "nccl" or args.share_gpu or args.frames or args.resident or args.no_lean or args.lean_parts is not None) and not args.rehearsal:
+    if (args.backend != "nccl" or args.share_gpu or args.frames or args.resident or args.no_lean or args.lean_parts is not None
+            or args.no_shared_prefix) and not args.rehearsal:
         raise SystemExit("--backend gloo, --share-gpu, --frames and --resident change what is measured: pass --rehearsal with them")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -269,6 +272,8 @@ def main():
             # a gather = as_world LOCAL copies: the host-side call count of a node.  (On one GPU every one of them is a
             # blit kernel on the GPU that is computing; on a node 7 of 8 are remote pulls.  An upper bound of the cost.)
             unet.W.rehearse_copies = args.as_world
+    if args.no_shared_prefix:
+        unet.share_cfg_prefix = False
     if args.ff_block_mb:
         unet.ff_block_bytes = args.ff_block_mb << 20
     if args.no_lean:

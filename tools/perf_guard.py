@@ -16,6 +16,8 @@ GUARDED = (
     "flash_attn_kernel<2, false, true>",                   # spatial self-attention
     "tattn2_kernel<320, 24>",                              # K7, second design
     "ff_fused_kernel<320>",                                # K8
+    "conv3x3_gn_kernel",                                   # K1 (level-0 3x3 convolutions, round 4)
+    "tconv_gn_kernel<12>",                                 # K3 (level-0 temporal convolutions at 24 frames, round 4)
 )
 
 
