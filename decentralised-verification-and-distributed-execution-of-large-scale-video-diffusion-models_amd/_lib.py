@@ -44,7 +44,6 @@ SIGNATURES = {
     "vdx_im2col_in_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vdx_rows_to_ncfhw_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "vdx_silu_f16": (_i, [_vp, _vp, _sz, _vp]),
-    "vdx_groupnorm_fused_finalize": (_i, [_i]),
     "vdx_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
     "vdx_groupnorm_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "vdx_groupnorm_workspace_part": (_sz, [_i, _i, _i, _i, _i]),

@@ -6,8 +6,6 @@
 // the number of 8-channel vectors per row, so every thread keeps a fixed channel vector
 // (coalesced 16-byte accesses, per-channel scale/shift held in registers).
 #include "vdx_common.h"
-#include <atomic>
-#include <mutex>
 
 // Rows of one sample per block: 128 for the big levels, halved until the grid has >= min_blocks blocks so the deep
 // levels (6912 rows in all at level 3) still spread over the 256 CUs.  The statistics pass stops at 256 blocks (one
@@ -28,10 +26,6 @@ struct GnP {
     int apply_rows;                          // rows of a sample per block of the apply pass
     float* partial;                  // [n_samples][nslabs][G][3]  (count, mean, M2)
     float* ab;                       // [n_samples][C][2]          (scale, shift)
-    // finalize inside the statistics kernel (round 5): the LAST block of a sample to finish merges the sample's slab triples
-    unsigned* tickets;               // [n_samples] arrival counters (zero between launches), or nullptr: separate finalize launch
-    const f16 *gamma, *beta;
-    float eps;
 };
 
 __device__ __forceinline__ f16x8 gn_load(const GnP& p, size_t row, int cv) {
@@ -54,8 +48,6 @@ __device__ __forceinline__ Moments merge(const Moments a, const Moments b) {
     const float n = a.n + b.n, d = b.mean - a.mean;
     return Moments{n, a.mean + d * (b.n / n), a.m2 + b.m2 + d * d * (a.n * b.n / n)};
 }
-
-__device__ __forceinline__ void gn_finalize_group(const GnP& p, const f16* gamma, const f16* beta, float eps, int sample, int g, int lane);
 
 __global__ void gn_partial_kernel(const GnP p) {
     // [2][krows][C] per-thread channel (mean, M2) + [krows] row counts; reduced to groups in a FIXED order (no float
@@ -135,30 +127,14 @@ __global__ void gn_partial_kernel(const GnP p) {
         dst[3 * g + 1] = m.mean;
         dst[3 * g + 2] = m.m2;
     }
-    if (!p.tickets) return;
-    // Finalize here instead of in a launch of its own (166 launches of ~6 us per XL forward): the block that arrives LAST at its
-    // sample's counter merges the sample's slab triples — the same code on the same triples in the same order as the
-    // separate kernel (gn_finalize_group), so the scale / shift pairs carry the same bits.  Release / acquire through
-    // agent-scope fences around the counter: the other blocks' triples were written on other XCDs (their L2s are not
-    // coherent with this one for plain accesses).  The counter is back at zero when the kernel ends.
-    __shared__ int last_;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned old = atomicAdd(&p.tickets[sample], 1u);
-        last_ = old == (unsigned)(p.nslabs - 1);
-        if (last_) atomicExch(&p.tickets[sample], 0u);
-    }
-    __syncthreads();
-    if (!last_) return;
-    __threadfence();
-    const int nwaves = blockDim.x >> 6, wave = tid >> 6;        // whole waves only (a block of 280 threads has a 24-lane tail)
-    if (wave >= nwaves) return;
-    for (int g = wave; g < p.G; g += nwaves) gn_finalize_group(p, p.gamma, p.beta, p.eps, sample, g, tid & 63);
 }
 
 // one wave per (sample, group): merge the slab triples in double, emit per-channel scale/shift
-__device__ __forceinline__ void gn_finalize_group(const GnP& p, const f16* gamma, const f16* beta, float eps, int sample, int g, int lane) {
+__global__ void gn_finalize_kernel(const GnP p, const f16* gamma, const f16* beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int sg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (sg >= p.n_samples * p.G) return;
+    const int sample = sg / p.G, g = sg % p.G;
     // Slab triples -> one (n, mean, M2) per (sample, group), in double and without a division per slab: with every
     // mean taken relative to K = the mean of slab 0,
     //     N = sum n_i,  S1 = sum n_i d_i,  S2 = sum n_i d_i^2,  Q = sum M2_i      (d_i = mean_i - K)
@@ -210,12 +186,6 @@ __device__ __forceinline__ void gn_finalize_group(const GnP& p, const f16* gamma
         dst[0] = a;
         dst[1] = (float)beta[c] - (float)mean * a;
     }
-}
-__global__ void gn_finalize_kernel(const GnP p, const f16* gamma, const f16* beta, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int sg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (sg >= p.n_samples * p.G) return;
-    gn_finalize_group(p, gamma, beta, eps, sg / p.G, sg % p.G, lane);
 }
 
 template <bool SILU>
@@ -275,32 +245,6 @@ extern "C" int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2,
     return vdx_groupnorm_part_f16(x, c1, ldx, x2, c2, ldx2, gamma, beta, eps, G, n_samples, rows_per_sample, silu, y, ldy,
                                   workspace, 0, stream);
 }
-// Arrival counters of the fused finalize: one static array, a range of GN_TICKETS_PER_STREAM counters per stream (launches of
-// one stream are ordered, so they can share a range; two streams must not).  More streams than ranges, or more samples than a
-// range: that call keeps the separate finalize launch.
-static std::atomic<int> g_gn_fused_finalize{1};
-extern "C" int vdx_groupnorm_fused_finalize(int on) {      // returns the previous setting; on < 0: query only
-    const int prev = g_gn_fused_finalize.load();
-    if (on >= 0) g_gn_fused_finalize.store(on ? 1 : 0);
-    return prev;
-}
-constexpr int GN_TICKET_STREAMS = 16, GN_TICKETS_PER_STREAM = 4096;
-static __device__ unsigned g_gn_tickets[GN_TICKET_STREAMS * GN_TICKETS_PER_STREAM];
-static unsigned* gn_ticket_range(hipStream_t st, int n_samples) {
-    static std::mutex mu;
-    static hipStream_t owner[GN_TICKET_STREAMS];
-    static int used = 0;
-    static unsigned* base = nullptr;
-    if (n_samples > GN_TICKETS_PER_STREAM) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_gn_tickets)) != hipSuccess) return nullptr;
-    for (int i = 0; i < used; ++i)
-        if (owner[i] == st) return base + (size_t)i * GN_TICKETS_PER_STREAM;
-    if (used == GN_TICKET_STREAMS) return nullptr;
-    owner[used] = st;
-    return base + (size_t)(used++) * GN_TICKETS_PER_STREAM;
-}
-
 // statistics (+ per-channel scale / shift) always; the apply pass unless `stats_only` (the fold into a following Linear)
 static int gn_run(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
                   const void* gamma, const void* beta, float eps, int G,
@@ -325,13 +269,9 @@ static int gn_run(const void* x, int c1, int ldx, const void* x2, int c2, int ld
     const int nt = gn_threads(p.nvec, &p.krows);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.nslabs, n_samples);
-    p.gamma = (const f16*)gamma; p.beta = (const f16*)beta; p.eps = eps;
-    p.tickets = nt >= 64 && g_gn_fused_finalize.load() ? gn_ticket_range(st, n_samples) : nullptr;        // (the fused finalize runs on whole waves)
     hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(nt), (2 * (size_t)p.krows * C + p.krows + 2 * (size_t)G * p.krows) * sizeof(float), st, p);
-    if (!p.tickets) {
-        const int nsg = n_samples * G;
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, st, p, (const f16*)gamma, (const f16*)beta, eps);
-    }
+    const int nsg = n_samples * G;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nsg + 3) / 4), dim3(256), 0, st, p, (const f16*)gamma, (const f16*)beta, eps);
     if (stats_only) return vdx_launch_status("vdx_groupnorm_f16 (statistics)");
     dim3 agrid((rows_per_sample + p.apply_rows - 1) / p.apply_rows, n_samples);
     if (silu)

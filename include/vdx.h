@@ -125,10 +125,6 @@ int vdx_gelu_f16(const void* x, void* y, size_t n, vdx_stream_t stream);
  *   4-D GN: rows_per_sample = H*W (sample = one frame); 5-D GN: rows_per_sample = F*H*W.
  * Two sources (x | x2) cover the skip concatenation in up blocks.
  * ---------------------------------------------------------------------------------------- */
-/* The statistics pass finalizes inside its own kernel (the last block of a sample merges the sample's slab triples: no
- * separate finalize launch; same bits).  vdx_groupnorm_fused_finalize(0) restores the separate launch (A/B timing, tests),
- * (1) re-enables, (-1) only queries; returns the previous setting.  Process-wide. */
-int vdx_groupnorm_fused_finalize(int on);
 size_t vdx_groupnorm_workspace(int n_samples, int rows_per_sample, int C, int G);
 /* y[M][C] = act( (x - mean) * rstd * gamma + beta ), act = SiLU if silu != 0                   */
 int vdx_groupnorm_f16(const void* x, int c1, int ldx, const void* x2, int c2, int ldx2,
