@@ -5,7 +5,7 @@ the only place the reference's path appears; nothing of the reference travels (t
     python tests/golden/make_ref_fixtures.py            # everything (about two minutes on 8 cores)
     python tests/golden/make_ref_fixtures.py planner    # only the planner sweep
 
-What is executed: `Distribution/strategies/{fsdp_chunked_coherent,fsdp_chunked,chunk_only}.py`, each loaded with
+What is executed: `Distribution/strategies/{fsdp_chunked_coherent,fsdp_chunked,chunk_only,fsdp}.py`, each loaded with
 `runpy.run_path(<file>, run_name="__main__")` so that its module body, `main()`, `DistributedVideoDiffuser.__init__`,
 `_denoise` and `__call__` run as written (argparse -> planner -> shared noise -> [ctx] -> CFG/DDIM loop -> gather ->
 ramp blend -> per-frame decode -> boundary metric -> CSV row).  World sizes 1, 2, 3, 4 and 8 as real processes over gloo.
@@ -41,7 +41,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/Distribution/strategies"
-FILES = {"coherent": "fsdp_chunked_coherent.py", "fsdp_chunked": "fsdp_chunked.py", "chunk_only": "chunk_only.py"}
+FILES = {"coherent": "fsdp_chunked_coherent.py", "fsdp_chunked": "fsdp_chunked.py", "chunk_only": "chunk_only.py", "fsdp": "fsdp.py"}
 TINY = dict(ch=(64, 128, 128, 128), cross=128, in_heads=2)      # == tests/ref_exec_standins.TINY
 WORLDS = (1, 2, 3, 4, 8)
 
@@ -92,6 +92,9 @@ NUMERIC = {
     "exact_chunk_only_cfg1": ("chunk_only", "-", 1, 8, 32, 10, 0, 4, "exact"),            # BASELINE cfg1: 8 frames @256x256, 10 steps
     "exact_fsdp_chunked_w2": ("fsdp_chunked", "-", 2, 14, 16, 3, 0, 4, "exact"),
     "exact_fsdp_mode_w2": ("coherent", "fsdp", 2, 6, 16, 3, 0, 4, "exact"),               # BASELINE cfg3's mode: both ranks the whole clip
+    # fsdp.py — the strategy file BASELINE cfg3 names (FSDPBenchmark: its own loop :141-153, literal 7.5, no scale_model_input,
+    # UNSEEDED noise: the harness seeds torch's global generator before the script starts; decode through pipe.decode_latents)
+    "exact_fsdp_file_w2": ("fsdp", "-", 2, 8, 16, 10, 0, 0, "exact"),
     # "oracle": the fp32 oracle UNet behind fp16 tensors — float arithmetic, compared within a stated tolerance
     "oracle_hybrid_ctx_w2": ("coherent", "hybrid_ctx", 2, 20, 16, 3, 0, 4, "oracle"),
     "oracle_chunk_only_cfg1": ("chunk_only", "-", 1, 8, 16, 10, 0, 4, "oracle"),
@@ -165,10 +168,18 @@ def install_stand_ins(tmp, seq):
         pipe = types.SimpleNamespace(unet=unet, text_encoder=TextEncoder(cross), vae=RecordingVAE(), tokenizer=Tokenizer(),
                                      scheduler=DDIMSchedulerRef())
         pipe.to = lambda dev: pipe
+
+        def decode_latents(lat):                        # fsdp.py:172 — (1,4,1,h,w) -> (1,3,1,H,W)
+            REC.z.append(lat[:, :, 0].detach().clone())
+            return standin_decode(lat[:, :, 0]).unsqueeze(2)
+        pipe.decode_latents = decode_latents
         pipe.from_pretrained_kwargs = {k: str(v) for k, v in kw.items()}
         REC.pipe = pipe
         return pipe
 
+    import huggingface_hub
+    if not hasattr(huggingface_hub, "HfFolder"):        # fsdp.py:26 imports a name newer huggingface_hub versions dropped; it never uses it
+        huggingface_hub.HfFolder = type("HfFolder", (), {})
     d = types.ModuleType("diffusers")
     d.DiffusionPipeline = types.SimpleNamespace(from_pretrained=from_pretrained)
     sys.modules["diffusers"] = d
@@ -183,7 +194,7 @@ def install_stand_ins(tmp, seq):
     cv.calcOpticalFlowFarneback = lambda a, b, *r: np.zeros(a.shape + (2,), np.float32)
     cv.remap = lambda f, mx, my, interp: f
     cv.VideoWriter_fourcc = lambda *a: 0
-    cv.VideoWriter = lambda *a: types.SimpleNamespace(write=lambda f: None, release=lambda: None)
+    cv.VideoWriter = lambda path, *a: types.SimpleNamespace(write=lambda f: None, release=lambda: open(path, "wb").close())
     sys.modules["cv2"] = cv
 
     torch.cuda.set_device = lambda *a, **k: None
@@ -237,6 +248,9 @@ def run_reference(file, argv, cwd):
 
 
 def argv_for(file, mode, T, chunk, ov, hw, steps, csv):
+    if file == "fsdp":
+        return ["--num_frames", str(T), "--steps", str(steps), "--height", str(hw * 8), "--width", str(hw * 8), "--device", "cpu",
+                "--out_csv", csv, "--model_id", "stand-in"]
     a = ["--num_frames", str(T), "--steps", str(steps), "--chunk_size", str(chunk), "--overlap", str(ov), "--height", str(hw * 8),
          "--width", str(hw * 8), "--device", "cpu", "--out_csv", csv, "--model_id", "stand-in"]
     if file == "coherent":
@@ -290,8 +304,23 @@ def worker(kind, outdir):
         REC.reset()
         KIND[0] = kind_
         csv = os.path.join(tmp, f"n_{name}_{rank}.csv")
+        if file == "fsdp":
+            torch.manual_seed(4321)                     # fsdp.py draws its noise unseeded (:133): fix the generator it draws from
         run_reference(file, argv_for(file, mode, T, chunk, ov, hw, steps, csv), tmp)
         if rank != 0:
+            continue
+        if file == "fsdp":
+            hdr, vals = open(csv).read().strip().split("\n")
+            d = dict(zip(hdr.split(","), vals.split(",")))
+            out = {"csv_header": np.array(hdr), "csv_mode": np.array(d["mode"]), "cs": int(d["chunk_size"]), "ov": int(d["overlap"]),
+                   "network_bytes": int(d["network_bytes"]), "csv_temp_instab": np.array(d["temp_instab"]), "T": T, "hw": hw, "steps": steps,
+                   "world": world, "ref_file": np.array(FILES[file]), "mode": np.array(mode), "unet_kind": np.array(kind_),
+                   "z": torch.stack([z[0] for z in REC.z]).numpy(),                  # the final latent, frame by frame, as handed to decode_latents (fp32)
+                   "x_first": REC.unet.calls[0][1].numpy(), "t_first": REC.unet.calls[0][0],
+                   "timesteps": np.array([t for t, _ in REC.unet.calls[:steps]]), "unet_calls": len(REC.unet.calls),
+                   "fsdp_kwargs": np.array(json.dumps(REC.fsdp_kwargs)), "seed": 4321}
+            np.savez_compressed(os.path.join(outdir, f"ref_exec_{name}.npz"), **out)
+            print(f"{name}: {out['unet_calls']} UNet calls, csv mode {d['mode']}", flush=True)
             continue
         hdr, vals = open(csv).read().strip().split("\n")
         d = dict(zip(hdr.split(","), vals.split(",")))

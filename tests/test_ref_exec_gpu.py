@@ -133,3 +133,23 @@ def test_whole_job_on_the_hip_unet_vs_executed_reference(gpu, name):
     e_lat = float((zs - z_ref).norm() / z_ref.norm())
     print(f"{name}: denoised chunks rel-L2 max {max(errs):.3e}, blended latent rel-L2 {e_lat:.3e} ({m['steps']} steps)")
     assert max(errs) <= 2e-2 and e_lat <= 2e-2
+
+
+def test_fsdp_py_loop_on_the_hip_path_vs_executed_reference(gpu):
+    """`fsdp.py`'s loop (BASELINE cfg3's strategy file, 10 steps) through the product's `denoise` from the SAME start."""
+    import vdx  # noqa: F401
+    from vdx.pipeline import DiffuserConfig, DistributedVideoDiffuser
+    from vdx.scheduler import DDIMScheduler
+    g = np.load(os.path.join(GOLD, "ref_exec_exact_fsdp_file_w2.npz"))
+    T, hw, steps = int(g["T"]), int(g["hw"]), int(g["steps"])
+    cfg = DiffuserConfig(num_frames=T, steps=steps, height=hw * 8, width=hw * 8, mode="fsdp", device="cuda", noise_device="cpu")
+    emb = text_table().to(gpu)
+    unet = ExactUNet()
+    d = DistributedVideoDiffuser(cfg, unet, DDIMScheduler(), emb[1:], emb[:1])
+    lat0 = torch.from_numpy(g["x_first"])[:1].to(gpu)
+    den = d.denoise(lat0.clone()).cpu().float()
+    want = torch.from_numpy(g["z"]).permute(1, 0, 2, 3).unsqueeze(0)
+    ulp = float(want.abs().max()) * 2.0 ** -10
+    worst = float((den - want).abs().max()) / ulp
+    print(f"fsdp.py loop: max |HIP - executed reference| = {worst:.2f} ulp(max) over {steps} steps")
+    assert [t for t, _ in unet.calls] == g["timesteps"].tolist() and worst <= 4.0 + steps / 8.0

@@ -188,3 +188,33 @@ def test_fsdp_wrap_arguments_of_the_executed_reference():
     # fsdp_chunked.py passes the same arguments (device_id = local_rank instead of current_device())
     for _, kw in json.loads(str(np.load(os.path.join(GOLD, "ref_exec_exact_fsdp_chunked_w2.npz"))["fsdp_kwargs"])):
         assert kw["sharding_strategy"] == "ShardingStrategy.FULL_SHARD" and "offload_params=True" in kw["cpu_offload"]
+
+
+def test_fsdp_py_loop_equals_the_executed_reference():
+    """`fsdp.py` — the strategy file BASELINE cfg3 names (`FSDPBenchmark.run`, :108-215): its own CFG loop (:141-153: literal
+    7.5, no `scale_model_input`), noise drawn unseeded (the harness seeded the global generator), per-frame decode through
+    `pipe.decode_latents`.  The oracle's `denoise` from the same start reproduces the final latent bit for bit; the CSV row
+    says mode "fsdp", chunk_size 0, overlap 0, network_bytes 0, empty boundary metrics."""
+    from oracle.ddim_ref import DDIMSchedulerRef
+    from oracle.pipeline_ref import denoise
+    import vdx  # noqa: F401
+    from vdx import metrics
+    g = np.load(os.path.join(GOLD, "ref_exec_exact_fsdp_file_w2.npz"))
+    T, hw, steps = int(g["T"]), int(g["hw"]), int(g["steps"])
+    # the start latent is what the script drew (:133-137; the generator also served the stand-in modules' constructors, so
+    # it is taken from the recorded first UNet input, whose two halves are the same tensor: `torch.cat([lat, lat])`, :143)
+    x_first = torch.from_numpy(g["x_first"])
+    lat0 = x_first[:1].clone()
+    assert tuple(x_first.shape) == (2, 4, T, hw, hw) and torch.equal(x_first[0], x_first[1]) and 0.9 < float(lat0.float().std()) < 1.1
+    sched = DDIMSchedulerRef()
+    sched.set_timesteps(steps)
+    assert sched.timesteps.tolist() == g["timesteps"].tolist() and int(g["unet_calls"]) == steps
+    emb = text_table()
+    lat = denoise(ExactUNet(), sched, lat0.clone(), emb[1:], emb[:1], 7.5, None)
+    z = torch.from_numpy(g["z"])                                               # (T, 4, h, w) fp32: lat.cpu().float()[:, :, i]
+    assert z.dtype == torch.float32 and torch.equal(lat[0].float().permute(1, 0, 2, 3), z)
+    assert str(g["csv_header"]).split(",") == metrics.CSV_HEADER and str(g["csv_mode"]) == "fsdp"
+    assert (int(g["cs"]), int(g["ov"]), int(g["network_bytes"]), str(g["csv_temp_instab"])) == (0, 0, 0, "")
+    calls = json.loads(str(g["fsdp_kwargs"]))
+    assert [c[0] for c in calls] == ["ExactUNet", "TextEncoder", "Linear"]
+    assert "offload_params=True" in calls[0][1]["cpu_offload"] and "offload_params=False" in calls[2][1]["cpu_offload"]     # fsdp.py:96: the VAE children stay on the GPU
