@@ -406,3 +406,27 @@ def test_lab_build_is_refused_as_the_product(tmp_path):
     assert r.returncode == 0 and "flags 64" in r.stdout, r.stderr[-1500:]
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "flags 0" in r.stdout, r.stderr[-1500:]
+
+
+def test_k1_k3_choice_depends_on_one_samples_shape_only():
+    """the fused GroupNorm + convolution kernels (K1, K3) and the apply pass + conv GEMM differ by one
+    rounding of the normalised value, so WHICH of them runs must not depend on the batch, the window count or the chip —
+    or a sample's bits would.  Pinned: at every level of the XL UNet the choice is the same for B in {1, 2} and any number of
+    images, it is "fused" at level 0 for F in {8, 12, 16, 24} and "not fused" at levels 1-3 and at the small latents of the
+    reference's other callers; and the C entry points really ignore the batch argument."""
+    lib = _lib.load()
+    widths = (320, 640, 1280, 1280)
+    for lvl, Cw in enumerate(widths):
+        hh, ww = 72 >> lvl, 128 >> lvl
+        for F_ in (8, 12, 16, 24):
+            k1 = {lib.vdx_conv3x3_gn_preferred(Cw, 0, Cw, B * F_, hh, ww) for B in (1, 2, 3)}
+            k1 |= {lib.vdx_conv3x3_gn_preferred(Cw, 0, Cw, n, hh, ww) for n in (1, 7, 11, 48, 1000)}
+            k3 = {lib.vdx_tconv_gn_preferred(Cw, Cw, B, F_, hh * ww) for B in (1, 2, 3, 16)}
+            assert k1 == {1 if lvl == 0 else 0}, (lvl, F_, k1)
+            assert k3 == {1 if lvl == 0 else 0}, (lvl, F_, k3)
+        # the up blocks' concat inputs at level 0 (320 + 320, 320 + 640 channels)
+        if lvl == 0:
+            assert {lib.vdx_conv3x3_gn_preferred(320, c2, 320, n, hh, ww) for c2 in (320, 640) for n in (8, 24, 48)} == {1}
+    for h_, w_ in ((32, 32), (40, 72), (16, 16), (16, 32)):               # cfg1 / InferNet caller latents: never the fused pair
+        assert lib.vdx_conv3x3_gn_preferred(320, 0, 320, 48, h_, w_) == 0
+        assert lib.vdx_tconv_gn_preferred(320, 320, 2, 24, h_ * w_) == (1 if ((h_ * w_ + 15) // 16) * 2 >= 512 else 0)
