@@ -50,6 +50,12 @@ def _lazy_place(module, tensor, shard=False):
 
 
 class UNet3DConditionModel(_unet.UNet3DConditionModel):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        # the unchanged script builds its CFG batch with torch.cat (fsdp_chunked_coherent.py:133): no tag from ops.cfg_input, so
+        # let the forward verify on the device that the two items are the same tensor and share the text-independent blocks
+        self.detect_cfg_duplicate = True
+
     def to(self, *a, **k):
         self._placed_by_to = True           # the script placed the module itself: replicate, do not shard
         return super().to(*a, **k)

@@ -83,6 +83,7 @@ class UNet3DConditionModel(nn.Module):
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
         self.fuse_temporal_attention = True    # K7 where the shape allows (False: always the separate kernels)
         self.share_cfg_prefix = True           # a CFG batch built by ops.cfg_input: the blocks before the first cross-attention run on ONE item (forward)
+        self.detect_cfg_duplicate = False      # untagged batch of two: COMPARE the halves on the device (one kernel + a host sync) before sharing
         self._text_ref = None                  # (encoder_hidden_states object, its version, (B, device), padded copy)
         self._text_kv: Dict[str, tuple] = {}   # cross-attention K / V^T of that text, per transformer
 
@@ -637,6 +638,12 @@ class UNet3DConditionModel(nn.Module):
         # batch of two, and the rows fan out at the cross-attention.  Same kernels on the same rows in the same order:
         # the output has the bits of the duplicated forward (tests/test_unet_gpu.py::test_cfg_shared_prefix_*).
         # The blocks of the prefix never take the split-K tail in EITHER form (its plan depends on the row count).
+        # A batch the caller built some other way (the reference's unchanged `torch.cat([lat]*2)` + ctx term, :133-137) carries
+        # no tag.  With `detect_cfg_duplicate` (set by the diffusers shim, i.e. for the unchanged script; off here) the two
+        # halves are COMPARED on the device — an exact test, one small kernel and one host sync per forward (~0.1 ms of a
+        # 170 ms step) — and the prefix is shared when, and only when, they are equal.
+        if not cfg_dup and self.detect_cfg_duplicate and self.share_cfg_prefix and B == 2:
+            cfg_dup = bool(torch.equal(sample[0], sample[1]))
         dup = bool(self.share_cfg_prefix and B == 2 and cfg_dup and c.down_block_types[0].startswith("CrossAttn"))
         self.last_forward_shared_prefix = dup
         B1 = 1 if dup else B

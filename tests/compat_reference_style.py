@@ -79,6 +79,12 @@ def main():
     lat = denoise(unet, base.clone())
     assert lat.shape == base.shape and bool(torch.isfinite(lat.float()).all())
     assert torch.equal(lat, denoise(plain_unet, base.clone())), "the FSDP wrapper changed the result"
+    # the shim's UNet verifies on the device that the script's torch.cat batch holds the same tensor twice and computes the
+    # text-independent blocks once; with that switched off the result must carry the same bits
+    assert plain_unet.last_forward_shared_prefix and plain_unet.detect_cfg_duplicate
+    plain_unet.detect_cfg_duplicate = False
+    assert torch.equal(lat, denoise(plain_unet, base.clone())) and not plain_unet.last_forward_shared_prefix
+    plain_unet.detect_cfg_duplicate = True
     frames = []
     for i in range(T):
         z = lat[:, :, i].float().to(device)                       # (the reference's blended latent is fp32)
