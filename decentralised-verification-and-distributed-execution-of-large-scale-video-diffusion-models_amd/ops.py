@@ -676,7 +676,10 @@ def temporal_attn_block(t, gamma, beta, wqkv_packed, wo_packed, bo, *, B, F, HW,
 
 # --------------------------------------------------------------------------------------------
 def cfg_input(lat, ctx, weight, out=None):
-    """fsdp_chunked_coherent.py:133-137: cat([lat]*2) (+ weight * ctx.repeat(F))."""
+    """fsdp_chunked_coherent.py:133-137: cat([lat]*2) (+ weight * ctx.repeat(F)).
+    The result is TAGGED as a known duplicate (`is_cfg_duplicate`): the UNet then computes its text-independent blocks once.
+    The tag is tied to torch's version counter, which torch operations bump and this library's kernels do NOT: never hand the
+    result to a vdx op as its `out=` (nothing in this package does)."""
     lib = _lib.load()
     b, Cc, F, H, W = lat.shape
     if b != 1 or not lat.is_contiguous():
