@@ -5,8 +5,8 @@ extern "C" int vdx_version(void) { return 1; }
 // 0 = the product build.  Bit per translation unit that was compiled with a lab macro (stamps / ablations).
 extern "C" int vdx_lab_gemm(void); extern "C" int vdx_lab_gemm_ws(void); extern "C" int vdx_lab_tattn_fused(void);
 extern "C" int vdx_lab_tattn2(void); extern "C" int vdx_lab_flash(void); extern "C" int vdx_lab_ff_fused(void);
-extern "C" int vdx_lab_conv_fused(void);
+extern "C" int vdx_lab_conv_fused(void); extern "C" int vdx_lab_xattn(void);
 extern "C" int vdx_build_flags(void) {
     return vdx_lab_gemm() | vdx_lab_gemm_ws() | vdx_lab_tattn_fused() | vdx_lab_tattn2() | vdx_lab_flash() | vdx_lab_ff_fused() |
-           vdx_lab_conv_fused();
+           vdx_lab_conv_fused() | vdx_lab_xattn();
 }

@@ -640,6 +640,38 @@ def ff_block(t, packed, *, M, eps=1e-5, out=None):
     return out
 
 
+def cross_attn_block_supported(inner: int, kv_len: int) -> bool:
+    return bool(_lib.load().vdx_cross_attn_block_supported(inner, kv_len))
+
+
+def cross_attn_block(t, packed, kv_packed, *, kv_len, n_items, rows_per_item, eps=1e-5, out=None):
+    """K5 (csrc/xattn.hip): t + to_out(softmax(q K^T) V), q = LayerNorm(t).W_q^T — the cross-attention sub-block of a spatial
+    transformer — in one kernel.  `packed`: packing.pack_k5 (LayerNorm's affine, the scale, the biases inside);
+    `kv_packed`: packing.pack_k5_kv of the text keys / values, [n_items][heads][3 units]; rows [n_items*rows_per_item][inner]."""
+    lib = _lib.load()
+    r, inner, ldt = _rows(t, "t")
+    M = n_items * rows_per_item
+    if r < M:
+        raise VdxError(f"cross_attn_block: t has {r} rows, need {M}")
+    if not lib.vdx_cross_attn_block_supported(inner, kv_len):
+        raise VdxError(f"cross_attn_block: inner={inner}, kv_len={kv_len} not supported by the fused kernel")
+    if packed.dtype != torch.float16 or packed.numel() * 2 != lib.vdx_cross_attn_block_pack_bytes(inner) or not packed.is_contiguous():
+        raise VdxError("cross_attn_block: packed blob does not match the kernel's layout (packing.pack_k5)")
+    if kv_packed.dtype != torch.float16 or kv_packed.numel() * 2 != n_items * lib.vdx_cross_attn_block_kv_bytes(inner) \
+            or not kv_packed.is_contiguous():
+        raise VdxError("cross_attn_block: key / value blob does not match the kernel's layout (packing.pack_k5_kv)")
+    if out is None:
+        out = torch.empty((M, inner), dtype=torch.float16, device=t.device)
+    orow, ocol, ldo = _rows(out, "out")
+    if orow < M or ocol < inner:
+        raise VdxError("cross_attn_block: out too small")
+    if out.data_ptr() == t.data_ptr():
+        raise VdxError("cross_attn_block: out may not alias t")
+    _lib.check(lib.vdx_cross_attn_block_f16(_p(t, "t"), ldt, _p(packed, "packed"), _p(kv_packed, "kv_packed"), int(kv_len), float(eps),
+                                            _p(out, "out"), ldo, n_items, rows_per_item, inner, _stream()), "vdx_cross_attn_block_f16")
+    return out
+
+
 def temporal_attn_block_supported(inner: int, F: int) -> bool:
     return bool(_lib.load().vdx_temporal_attn_block_supported(inner, F))
 

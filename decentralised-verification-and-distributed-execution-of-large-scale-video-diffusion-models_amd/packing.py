@@ -213,6 +213,80 @@ def pack_k7b(wq, wk, wv, wo, gamma, beta, bo, scale: float) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+# K5 (csrc/xattn.hip): the cross-attention sub-block in one kernel.  The static blob is K7B's with the k / v parts
+# taken out: [heads][5 units] q stream (W_q' = c.W_q.diag(gamma), c = scale.log2 e), the output projection exactly as
+# K7B packs it (k index permuted to the order in which P.V leaves the accumulators), fp32 q bias c.W_q.beta, fp32 b_o.
+# The text keys / values are packed ONCE PER PROMPT (`pack_k5_kv`, torch ops on the device) into MFMA-fragment order:
+# per (batch item, head) 3 units of 8 KB = K fragments [kt 5][j 4][lane 64][4 halfs] (lane (n16, q4) holds
+# K[16kt + n16][64h + 16j + 4q4 + e]), V fragments [kt 5][dt 4][lane][4] (V[16kt + 4q4 + e][64h + 16dt + n16]), zero pad.
+# ---------------------------------------------------------------------------------------------
+K5_WIDTHS = (320,)
+K5_KEY_SLOTS = 80
+
+
+def _k7b_pack_wo(wo16: torch.Tensor, heads: int, inner: int):
+    dev = wo16.device
+    ar = lambda n: torch.arange(n, device=dev)             # noqa: E731
+    chunk, j8 = ar(4)[:, None], ar(8)[None, :]
+    kperm = 16 * (j8 >> 2) + 4 * chunk + (j8 & 3)                               # [4][8] channel inside a 32-wide k step
+    n = ar(16)
+
+    def cols(base, ntile):
+        jt = ar(ntile)[:, None]
+        return base + 32 * (jt // 2) + 8 * (n[None, :] >> 2) + 4 * (jt % 2) + (n[None, :] & 3)     # [ntile][16]
+
+    parts = []
+    for cg in range(inner // 128):
+        col = cols(128 * cg, 8)
+        u = torch.empty((heads, 2, 8, 16, 4, 8), dtype=torch.float16, device=dev)
+        for h in range(heads):
+            for kk in range(2):
+                ch = 64 * h + 32 * kk + kperm
+                u[h, kk] = wo16[col[:, :, None, None], ch[None, None]]
+        parts.append(_k7_slot_swizzle(u).reshape(-1))
+    col = cols(128 * (inner // 128), 4)
+    u = torch.empty((heads, 2, 4, 16, 4, 8), dtype=torch.float16, device=dev)
+    for h in range(heads):
+        for kk in range(2):
+            ch = 64 * h + 32 * kk + kperm
+            u[h, kk] = wo16[col[:, :, None, None], ch[None, None]]
+    parts.append(_k7_slot_swizzle(u).reshape(-1))
+    return parts
+
+
+def pack_k5(wq, wo, gamma, beta, bo, scale: float) -> torch.Tensor:
+    """to_q [inner][inner], to_out.0 [inner][inner] + bias, norm2's gamma / beta -> fp16 tensor holding the static blob."""
+    inner = wq.shape[0]
+    assert inner in K5_WIDTHS and inner % 128 == 64 and tuple(wq.shape) == (inner, inner) and tuple(wo.shape) == (inner, inner)
+    heads, km = inner // 64, inner // 64
+    dev = wq.device
+    f = lambda x: x.to(device=dev, dtype=torch.float32)    # noqa: E731
+    wq, wo, gamma, beta, bo = (f(x) for x in (wq, wo, gamma, beta, bo))
+    c = float(scale) * 1.4426950408889634
+    q16 = (wq * gamma[None, :] * c).half()
+    bq = c * (wq @ beta)
+    uq = _k7_slot_swizzle(_k7b_units(q16, heads, km)).reshape(-1)              # [h][5][8][16][4][8]
+    vec = torch.cat([bq, bo]).contiguous().view(torch.float16)
+    return torch.cat([uq] + _k7b_pack_wo(wo.half(), heads, inner) + [vec]).contiguous()
+
+
+def pack_k5_kv(k_rows: torch.Tensor, vt: torch.Tensor, n_items: int, text_pad: int) -> torch.Tensor:
+    """k_rows [n_items*text_pad][inner] (text keys, rows past the text are ignored by the kernel's mask), vt [inner][n_items*
+    text_pad] (text values, transposed: what the un-fused path keeps) -> [n_items][heads][3 * 4096] fp16 fragment blobs."""
+    inner = k_rows.shape[1]
+    heads, ks = inner // 64, K5_KEY_SLOTS
+    assert inner in K5_WIDTHS and text_pad >= ks and k_rows.shape[0] == n_items * text_pad and tuple(vt.shape) == (inner, n_items * text_pad)
+    K = k_rows.reshape(n_items, text_pad, inner)[:, :ks]                                             # [item][key][c]
+    V = vt.reshape(inner, n_items, text_pad).permute(1, 2, 0)[:, :ks]                                # [item][key][c]
+    kf = K.reshape(n_items, 5, 16, heads, 4, 4, 4).permute(0, 3, 1, 4, 5, 2, 6)                      # [item][h][kt][j][q4][n16][e]
+    vf = V.reshape(n_items, 5, 4, 4, heads, 4, 16).permute(0, 4, 1, 5, 2, 6, 3)                      # [item][h][kt][dt][q4][n16][e]
+    out = torch.zeros((n_items, heads, 3 * 4096), dtype=torch.float16, device=k_rows.device)
+    out[:, :, :5120] = kf.reshape(n_items, heads, 5120)
+    out[:, :, 5120:10240] = vf.reshape(n_items, heads, 5120)
+    return out.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
 # K8 (csrc/ff_fused.hip): the feed-forward sub-block in one kernel.  LayerNorm's affine is folded into the first
 # projection: W1' = W1.diag(gamma), b1' = b1 + W1.beta (the initial accumulators of val / gate).  The hidden width is
 # cut into chunks of 64; a chunk's blob is 15 units of 8 KB in K7B's unit format: (val, gate) for each of the five K-64

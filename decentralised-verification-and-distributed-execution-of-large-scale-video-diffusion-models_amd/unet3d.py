@@ -78,6 +78,7 @@ class UNet3DConditionModel(nn.Module):
         self.lean_attn = True          # (with ff_block_bytes set) spatial self-attention over image halves
         self.fold_norm_proj_in = True  # GroupNorm -> proj_in as per-sample weights where the Linear is weights-stationary
         self.fuse_ff = True            # K8 where the width allows (False: LayerNorm, GEGLU GEMM, GEMM + residual)
+        self.fuse_cross_attn = True    # K5 where the width and the text length allow (False: LayerNorm, q GEMM, flash attention, GEMM + residual)
         self.fuse_conv_gn = True       # K1 where it is faster — level 0 (False: GroupNorm apply pass + 3x3-conv GEMM; "always": wherever the shape allows, tests)
         self.fuse_tconv = True         # K3 where it is faster — level 0 (False: GroupNorm apply pass + temporal-conv GEMM; "always": wherever the shape allows, tests)
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
@@ -162,6 +163,10 @@ class UNet3DConditionModel(nn.Module):
                 # K8: the feed-forward sub-block as one kernel, norm3 folded into its first projection (csrc/ff_fused.hip)
                 put(b + ".ff.k8", packing.pack_k8(sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"], sd[b + ".ff.net.2.weight"],
                                                  sd[b + ".ff.net.2.bias"], sd[b + ".norm3.weight"], sd[b + ".norm3.bias"]))
+            if not temporal and sd[b + ".attn2.to_q.weight"].shape[0] in packing.K5_WIDTHS:
+                # K5: the cross-attention sub-block as one kernel, norm2 folded into its query projection (csrc/xattn.hip)
+                put(b + ".attn2.k5", packing.pack_k5(packing.pack_conv1x1(sd[b + ".attn2.to_q.weight"]), packing.pack_conv1x1(sd[b + ".attn2.to_out.0.weight"]),
+                                                   sd[b + ".norm2.weight"], sd[b + ".norm2.bias"], sd[b + ".attn2.to_out.0.bias"], c.attention_head_dim ** -0.5))
             if temporal and sd[b + ".attn1.to_q.weight"].shape[0] in packing.K7B_WIDTHS:
                 # K7, second design: one blob per attention sub-block with its LayerNorm folded in (csrc/tattn2.hip)
                 for a, nm in (("attn1", "norm1"), ("attn2", "norm2")):
@@ -502,17 +507,37 @@ class UNet3DConditionModel(nn.Module):
         t = ops.gemm(o, W[b + ".attn1.to_out.0.weight"], M=M, bias=W[b + ".attn1.to_out.0.bias"], residual=t)
         del o
         # --- cross-attention over the (padded) text tokens; all F frames of a sample share K/V
-        ln = ops.layernorm(t, W[b + ".norm2.weight"], W[b + ".norm2.bias"], M=M)
-        q = ops.gemm(ln, W[b + ".attn2.to_q.weight"], M=M)
-        del ln
         nb = ehs_pad.shape[0] // TEXT_PAD
+        k5 = self.fuse_cross_attn and b + ".attn2.k5" in W and ops.cross_attn_block_supported(C, self._text_len)
         kv = self._text_kv.get(p)
         if kv is None:
             k = ops.gemm(ehs_pad, W[b + ".attn2.to_k.weight"], M=ehs_pad.shape[0])
             vt = ops.gemm(W[b + ".attn2.to_v.weight"], ehs_pad, M=C)              # [C][nb*TEXT_PAD]
-            self._text_kv[p] = (k, vt)
-        else:
-            k, vt = kv
+            kv = self._text_kv[p] = (k, vt, packing.pack_k5_kv(k, vt, nb, TEXT_PAD) if k5 else None)
+        k, vt, kvb = kv
+        if k5 and kvb is None:
+            kvb = packing.pack_k5_kv(k, vt, nb, TEXT_PAD)
+            self._text_kv[p] = (k, vt, kvb)
+        if k5:
+            # K5 (level 0): LayerNorm -> q -> softmax(q K^T) V -> to_out + residual in one kernel; the text keys / values were
+            # packed once per prompt.  A shared-prefix batch (`dup`): the same rows against each item's text in turn.
+            if dup:
+                t2 = torch.empty((M_out, C), dtype=torch.float16, device=x.device)
+                for i in range(nb):
+                    ops.cross_attn_block(t, W[b + ".attn2.k5"], kvb[i:i + 1], kv_len=self._text_len, n_items=1, rows_per_item=M, out=t2[i * M:(i + 1) * M])
+            else:
+                t2 = ops.cross_attn_block(t, W[b + ".attn2.k5"], kvb, kv_len=self._text_len, n_items=nb, rows_per_item=M // nb)
+            t = self._ff(b, t2, M_out)
+            del t2
+            if not dup:
+                return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
+            out = torch.empty((M_out, C), dtype=torch.float16, device=x.device)
+            for i in range(nb):
+                ops.gemm(t[i * M:(i + 1) * M], W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x, out=out[i * M:(i + 1) * M])
+            return out
+        ln = ops.layernorm(t, W[b + ".norm2.weight"], W[b + ".norm2.bias"], M=M)
+        q = ops.gemm(ln, W[b + ".attn2.to_q.weight"], M=M)
+        del ln
         if dup:
             # one query tensor, the keys / values of each item in turn; the residual rows (and, at the block's end, the
             # transformer's input rows) are the shared item's for both — two launches over half the rows each, no copy

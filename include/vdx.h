@@ -34,7 +34,7 @@ const char* vdx_last_error(void);
 int vdx_version(void);
 /* 0 for the product build.  Non-zero: some translation unit was compiled with a lab macro (phase stamps, ablations — timing
  * only, some variants compute wrong results); bit = unit (1 gemm, 2 gemm_ws, 4 tattn_fused, 8 tattn2, 16 flash, 32 ff_fused,
- * 64 conv_fused).  The Python binding refuses such a library unless VDX_ALLOW_LAB_BUILD=1 (the lab tools set it). */
+ * 64 conv_fused, 128 xattn).  The Python binding refuses such a library unless VDX_ALLOW_LAB_BUILD=1 (the lab tools set it). */
 int vdx_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -247,6 +247,20 @@ int vdx_temporal_attn_block_f16(const void* t, int ldt, const void* gamma, const
                                 const void* wqkv_packed, const void* wo_packed, const void* bo,
                                 void* out, int ldo, int B, int F, int HW, int inner, float scale,
                                 vdx_stream_t stream);
+
+/* K5 (csrc/xattn.hip) — the cross-attention sub-block of diffusers' BasicTransformerBlock in a spatial transformer
+ * (`t = t + attn2(norm2(t), encoder_hidden_states)`; call site fsdp_chunked_coherent.py:140) as one kernel:
+ *   out[r] = t[r] + W_o . softmax_k( c . (W_q LN(t[r]))_h . K[item(r)]_h[k] ) V[item(r)]_h + b_o      per head h, k < kv_len
+ * t / out: [n_items * rows_per_item][inner] fp16 rows, item(r) = r / rows_per_item; `packed`: vdx/packing.py pack_k5 (q units
+ * with LayerNorm's affine and the scale folded in, output-projection units, fp32 q bias, fp32 b_o;
+ * vdx_cross_attn_block_pack_bytes bytes); `kv_packed`: the text keys / values of every item in MFMA-fragment order
+ * (pack_k5_kv: n_items * vdx_cross_attn_block_kv_bytes bytes), 80 key slots of which the first kv_len are used.
+ * out may not alias t.  Supported: inner 320, 1 <= kv_len <= 80.                                                          */
+int vdx_cross_attn_block_supported(int inner, int kv_len);
+size_t vdx_cross_attn_block_pack_bytes(int inner);
+size_t vdx_cross_attn_block_kv_bytes(int inner);
+int vdx_cross_attn_block_f16(const void* t, int ldt, const void* packed, const void* kv_packed, int kv_len, float eps,
+                             void* out, int ldo, int n_items, int rows_per_item, int inner, vdx_stream_t stream);
 
 /* K7, second design (csrc/tattn2.hip) — the same sub-block (`s = s + attn(LN(s))`; call site
  * fsdp_chunked_coherent.py:140) with LayerNorm's affine, the softmax scale and all biases folded into ONE packed blob

@@ -126,7 +126,9 @@ def test_unet_weight_ingest_covers_every_diffusers_key():
     # + the K8 blobs (csrc/ff_fused.hip): the ten level-0 feed-forwards (5 spatial + 5 temporal transformers) as 300 units
     #   of 8 KB + the fp32 biases (2 x 1280 + 320)
     k8 = 10 * (300 * 4096 + 2 * (2 * 1280 + 320))
-    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7 + k8
+    # + the K5 blobs (csrc/xattn.hip): the five level-0 cross-attentions as 50 units of 4096 halfs + the two fp32 bias vectors
+    k5 = 5 * (50 * 4096 + 2 * 2 * 320)
+    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7 + k8 + k5
     assert m.config.in_channels == 4
     sd["bogus.weight"] = torch.empty(1, device="meta")
     with pytest.raises(_lib.VdxError):

@@ -852,6 +852,66 @@ def test_temporal_attn_block2_fused(gpu, B, Fr, HW):
     assert torch.equal(wide_out[:, :inner], out) and bool((wide_out[:, inner:] == 7.0).all())
 
 
+def _cross_block_ref(t, gamma, beta, wq, wk, wv, wo, bo, ehs, n_items, rows, heads):
+    """fp32 statement of `t + attn2(norm2(t), encoder_hidden_states)` per batch item."""
+    inner = t.shape[1]
+    ln = F.layer_norm(t, (inner,), gamma, beta, 1e-5)
+    q = (ln @ wq.t()).reshape(n_items, rows, heads, 64).permute(0, 2, 1, 3)
+    k = (ehs @ wk.t()).reshape(n_items, -1, heads, 64).permute(0, 2, 1, 3)
+    v = (ehs @ wv.t()).reshape(n_items, -1, heads, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(n_items * rows, inner)
+    return t + o @ wo.t() + bo
+
+
+@pytest.mark.parametrize("n_items,rows,kv_len", [(2, 2 * 9216, 77), (1, 1000, 77), (3, 192, 5), (2, 50, 80), (1, 300 * 192, 77), (2, 4 * 9216 + 64, 33)])
+def test_cross_attn_block_fused(gpu, n_items, rows, kv_len):
+    """K5 (csrc/xattn.hip, inner 320): LayerNorm (folded into the packed weights) -> q -> scores against the item's text
+    keys -> softmax -> P.V -> to_out + bias + residual in one kernel, against the fp32 statement of the sub-block (SURVEY
+    A.5) and against the un-fused kernels (LayerNorm, q GEMM, flash attention on the padded text, output GEMM).  Texts of
+    77 tokens (CLIP), of 5, of 33 and of the full 80 slots; row counts that fill no tile, exactly one, many (a workgroup walks
+    several: the next tile's rows are fetched behind the projection), items whose last tile is ragged."""
+    ops, packing = _ops()
+    inner, heads, cross, pad = 320, 5, 128, 128
+    g = torch.Generator().manual_seed(n_items + rows + kv_len)
+    M = n_items * rows
+    t = h(torch.randn(M, inner, generator=g) * 1.5 + 0.3)
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    wq, wo = h(torch.randn(inner, inner, generator=g) * 0.09), h(torch.randn(inner, inner, generator=g) * 0.05)
+    wk, wv = h(torch.randn(inner, cross, generator=g) * 0.12), h(torch.randn(inner, cross, generator=g) * 0.09)
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    ehs = h(torch.randn(n_items, kv_len, cross, generator=g))
+    d = lambda x: x.half().to(gpu)   # noqa: E731
+    # the text keys / values as the un-fused path keeps them: k rows of the zero-padded text, V^T
+    ehs_pad = torch.zeros(n_items * pad, cross)
+    ehs_pad.view(n_items, pad, cross)[:, :kv_len] = ehs
+    k_rows = ops.gemm(d(ehs_pad), d(wk), M=n_items * pad)
+    vt = ops.gemm(d(wv), d(ehs_pad), M=inner)
+    ref = _cross_block_ref(t, gamma, beta, wq, wk, wv, wo, bo, ehs, n_items, rows, heads)
+    assert ops.cross_attn_block_supported(inner, kv_len) and not ops.cross_attn_block_supported(inner, 81) and not ops.cross_attn_block_supported(640, 77)
+    blob = packing.pack_k5(wq, wo, gamma, beta, bo, 0.125).to(gpu)
+    kvb = packing.pack_k5_kv(k_rows, vt, n_items, pad)
+    out = ops.cross_attn_block(d(t), blob, kvb, kv_len=kv_len, n_items=n_items, rows_per_item=rows)
+    close(out, ref, tol=5e-3)
+    ln = ops.layernorm(d(t), d(gamma), d(beta), M=M)
+    q = ops.gemm(ln, d(wq), M=M)
+    o = ops.flash_attn(q, k_rows, vt, n_seq=n_items, sq=rows, skv=kv_len, skv_pad=pad, heads=heads, seq_per_kv=1, scale=0.125)
+    unf = ops.gemm(o, d(wo), M=M, bias=d(bo), residual=d(t))
+    close(out, unf.float().cpu(), tol=5e-3)
+    out2 = ops.cross_attn_block(d(t), blob, kvb, kv_len=kv_len, n_items=n_items, rows_per_item=rows)
+    assert torch.equal(out, out2)
+    # an item's rows carry the same bits wherever the item sits in the batch (tiles are aligned to items; the head order
+    # is a function of the tile's position inside its item)
+    if n_items > 1:
+        last = ops.cross_attn_block(d(t)[(n_items - 1) * rows:], blob, kvb[n_items - 1:].contiguous(), kv_len=kv_len, n_items=1, rows_per_item=rows)
+        assert torch.equal(last, out[(n_items - 1) * rows:])
+    wide_in = torch.zeros(M, inner + 64, dtype=torch.float16, device=gpu)
+    wide_in[:, :inner] = d(t)
+    wide_out = torch.full((M, inner + 8), 7.0, dtype=torch.float16, device=gpu)
+    ops.cross_attn_block(wide_in[:, :inner], blob, kvb, kv_len=kv_len, n_items=n_items, rows_per_item=rows, out=wide_out[:, :inner])
+    assert torch.equal(wide_out[:, :inner], out) and bool((wide_out[:, inner:] == 7.0).all())
+
+
 @pytest.mark.parametrize("Fr,HW", [(24, 1100), (16, 37), (12, 700)])
 def test_temporal_attn_block2_batch_invariant(gpu, Fr, HW):
     """A sample's result has the same bits wherever it sits in the batch and whatever else is in it: tiles are aligned
