@@ -432,3 +432,58 @@ def test_k1_k3_choice_depends_on_one_samples_shape_only():
     for h_, w_ in ((32, 32), (40, 72), (16, 16), (16, 32)):               # cfg1 / InferNet caller latents: never the fused pair
         assert lib.vdx_conv3x3_gn_preferred(320, 0, 320, 48, h_, w_) == 0
         assert lib.vdx_tconv_gn_preferred(320, 320, 2, 24, h_ * w_) == (1 if ((h_ * w_ + 15) // 16) * 2 >= 512 else 0)
+
+
+@pytest.mark.parametrize("kv_len,rot,item", [(77, 0, 0), (77, 3, 1), (5, 1, 1), (80, 4, 0), (33, 2, 1)])
+def test_k5_packing_matches_kernel_indexing(kv_len, rot, item):
+    """packing.pack_k5 / pack_k5_kv against a lane-level walk through csrc/xattn.hip's own addressing (tests/k5_emulator.py:
+    the q stream and the output projection of tattn2's unit format, the per-prompt key / value fragment blobs, the MFMA lane
+    maps, the masked key slots), compared with the fp32 statement of the cross-attention sub-block on one 48-row
+    group of batch item `item`."""
+    import numpy as np
+    import torch.nn.functional as Fn
+    from k5_emulator import Wave5
+    from k7b_emulator import p0
+    from vdx import packing
+    inner, heads, cross, pad, n_items = 320, 5, 96, 128, 2
+    g = torch.Generator().manual_seed(11 + kv_len + rot)
+    h = lambda x: x.half().float()    # noqa: E731
+    t = h(torch.randn(48, inner, generator=g) * 1.5 + 0.3)
+    gamma, beta = h(1 + 0.2 * torch.randn(inner, generator=g)), h(0.1 * torch.randn(inner, generator=g))
+    wq, wo = h(torch.randn(inner, inner, generator=g) * 0.09), h(torch.randn(inner, inner, generator=g) * 0.05)
+    wk, wv = h(torch.randn(inner, cross, generator=g) * 0.12), h(torch.randn(inner, cross, generator=g) * 0.09)
+    bo = h(0.1 * torch.randn(inner, generator=g))
+    ehs = h(torch.randn(n_items, kv_len, cross, generator=g))
+    ehs_pad = torch.zeros(n_items, pad, cross)
+    ehs_pad[:, :kv_len] = ehs
+    k_rows = h(ehs_pad.reshape(-1, cross) @ wk.t())                            # what the un-fused path's K GEMM leaves (fp16)
+    vt = h(wv @ ehs_pad.reshape(-1, cross).t())                                # and its V^T GEMM
+    ln = Fn.layer_norm(t, (inner,), gamma, beta, 1e-5)
+    q = (ln @ wq.t()).reshape(48, heads, 64).permute(1, 0, 2)
+    kk_ = k_rows.reshape(n_items, pad, heads, 64)[item, :kv_len].permute(1, 0, 2)
+    vv_ = vt.t().reshape(n_items, pad, heads, 64)[item, :kv_len].permute(1, 0, 2)
+    a = torch.softmax(q @ kk_.transpose(-1, -2) * 0.125, -1) @ vv_
+    ref = (t + a.permute(1, 0, 2).reshape(48, inner) @ wo.t() + bo).numpy()
+    blob = packing.pack_k5(wq, wo, gamma, beta, bo, 0.125)
+    kvb = packing.pack_k5_kv(k_rows.half(), vt.half(), n_items, pad)
+    lib = _lib.load()
+    assert blob.dtype == torch.float16 and blob.numel() * 2 == lib.vdx_cross_attn_block_pack_bytes(inner)
+    assert kvb.numel() * 2 == n_items * lib.vdx_cross_attn_block_kv_bytes(inner)
+    out = Wave5(blob.numpy(), kvb.numpy(), item, rot, kv_len).run(p0(t.numpy(), 1e-5), t.numpy())
+    assert np.abs(out - ref).max() <= 3e-3 * np.abs(ref).max() + 3e-3
+
+
+def test_k5_counted_waits_match_the_emitted_isa(tmp_path):
+    """The same check as for K7 / K8 on csrc/xattn.hip (K5): all 45 steps — DMA pieces, plain loads, stores and the counted
+    `s_waitcnt vmcnt(N)` of every step as tools/k5_check_waits.py derives them from the schedule, against the emitted ISA."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    pkg = os.path.join(ROOT, "decentralised-verification-and-distributed-execution-of-large-scale-video-diffusion-models_amd")
+    out = tmp_path / "xattn.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "--cuda-device-only", "-S",
+                    "-I", os.path.join(ROOT, "include"), "-I", os.path.join(pkg, "csrc"), os.path.join(pkg, "csrc", "xattn.hip"), "-o", str(out)],
+                   check=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k5_check_waits.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 mismatching" in r.stdout, r.stdout + r.stderr
