@@ -65,6 +65,8 @@ SIGNATURES = {
     "vdx_ff_block_supported": (_i, [_i]),
     "vdx_ff_block_pack_bytes": (_sz, [_i]),
     "vdx_ff_block_f16": (_i, [_vp, _i, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "vdx_ff_block_proj_pack_bytes": (_sz, [_i]),
+    "vdx_ff_block_proj_f16": (_i, [_vp, _i, _vp, _f, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "vdx_cross_attn_block_supported": (_i, [_i, _i]),
     "vdx_cross_attn_block_pack_bytes": (_sz, [_i]),
     "vdx_cross_attn_block_kv_bytes": (_sz, [_i]),

@@ -609,9 +609,11 @@ def ff_block_supported(inner: int) -> bool:
     return bool(_lib.load().vdx_ff_block_supported(inner))
 
 
-def ff_block(t, packed, *, M, eps=1e-5, out=None):
+def ff_block(t, packed, *, M, eps=1e-5, out=None, proj=None):
     """K8 (csrc/ff_fused.hip): t + ff(LayerNorm(t)) — GEGLU feed-forward of a transformer block — in one kernel;
-    LayerNorm's affine and the biases are inside `packed` (packing.pack_k8)."""
+    LayerNorm's affine and the biases are inside `packed` (packing.pack_k8).
+    `proj` = (tail blob of packing.pack_k8_proj, x, xrows): the transformer's proj_out and its residual run behind the
+    feed-forward in the same kernel — out[r] = x[r % xrows] + W_p . (t[r] + ff(LayerNorm(t[r]))) + b_p, xrows = M or M / 2."""
     lib = _lib.load()
     r, inner, ldt = _rows(t, "t")
     if r < M:
@@ -627,16 +629,29 @@ def ff_block(t, packed, *, M, eps=1e-5, out=None):
         raise VdxError("ff_block: out too small")
     if out.data_ptr() == t.data_ptr():
         raise VdxError("ff_block: out may not alias t")
-    rec = PROFILE is not None and _profiled(f"ff_fused_kernel<{inner}>")
+    name = f"ff_fused_kernel<{inner}, {'true' if proj is not None else 'false'}>"
+    rec = PROFILE is not None and _profiled(name)
     if rec:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(lib.vdx_ff_block_f16(_p(t, "t"), ldt, _p(packed, "packed"), float(eps), _p(out, "out"), ldo, M, inner, _stream()),
-               "vdx_ff_block_f16")
+    if proj is None:
+        _lib.check(lib.vdx_ff_block_f16(_p(t, "t"), ldt, _p(packed, "packed"), float(eps), _p(out, "out"), ldo, M, inner, _stream()),
+                   "vdx_ff_block_f16")
+    else:
+        blob, x, xrows = proj
+        xr, xc, ldx = _rows(x, "x")
+        if xc < inner or xr < xrows or xrows not in (M, M // 2) or (xrows != M and 2 * xrows != M):
+            raise VdxError(f"ff_block: x {tuple(x.shape)} / xrows {xrows} do not pair with M = {M} rows")
+        if blob.dtype != torch.float16 or blob.numel() * 2 != lib.vdx_ff_block_proj_pack_bytes(inner) or not blob.is_contiguous():
+            raise VdxError("ff_block: proj blob does not match the kernel's layout (packing.pack_k8_proj)")
+        if out.data_ptr() == x.data_ptr():
+            raise VdxError("ff_block: out may not alias x")
+        _lib.check(lib.vdx_ff_block_proj_f16(_p(t, "t"), ldt, _p(packed, "packed"), float(eps), _p(x, "x"), ldx, int(xrows), _p(blob, "proj"),
+                                             _p(out, "out"), ldo, M, inner, _stream()), "vdx_ff_block_proj_f16")
     if rec:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        PROFILE.append((f"ff_fused_kernel<{inner}>", 2.0 * M * inner * 12 * inner, ev0, ev1, (M, inner, 12 * inner)))
+        PROFILE.append((name, 2.0 * M * inner * (12 + (1 if proj is not None else 0)) * inner, ev0, ev1, (M, inner, 12 * inner)))
     return out
 
 

@@ -212,6 +212,17 @@ def pack_k7b(wq, wk, wv, wo, gamma, beta, bo, scale: float) -> torch.Tensor:
     return torch.cat([qkv] + parts + [vec]).contiguous()
 
 
+def pack_k8_proj(wp, bp) -> torch.Tensor:
+    """The transformer's proj_out [inner][inner] + bias as the TAIL of K8 (csrc/ff_fused.hip, PO): 25 units in tattn2's
+    output-projection format with the natural k order, fp32 b_p."""
+    inner = wp.shape[0]
+    assert inner in K8_WIDTHS and tuple(wp.shape) == (inner, inner)
+    dev = wp.device
+    parts = _k7b_pack_wo(wp.to(device=dev, dtype=torch.float32).half(), inner // 64, inner, natural=True)
+    vec = bp.to(device=dev, dtype=torch.float32).contiguous().view(torch.float16)
+    return torch.cat(parts + [vec]).contiguous()
+
+
 # ---------------------------------------------------------------------------------------------
 # K5 (csrc/xattn.hip): the cross-attention sub-block in one kernel.  The static blob is K7B's with the k / v parts
 # taken out: [heads][5 units] q stream (W_q' = c.W_q.diag(gamma), c = scale.log2 e), the output projection exactly as
@@ -224,11 +235,14 @@ K5_WIDTHS = (320,)
 K5_KEY_SLOTS = 80
 
 
-def _k7b_pack_wo(wo16: torch.Tensor, heads: int, inner: int):
+def _k7b_pack_wo(wo16: torch.Tensor, heads: int, inner: int, natural: bool = False):
+    """tattn2's output-projection units.  `natural`: the k index in its natural order (lane quad q holds channels 8q .. 8q+7 of a
+    32-wide k step: the B operand is a tile pair of fp16-rounded accumulators, K8's tail) instead of the order in which P.V leaves
+    the accumulators (K7 / K5)."""
     dev = wo16.device
     ar = lambda n: torch.arange(n, device=dev)             # noqa: E731
     chunk, j8 = ar(4)[:, None], ar(8)[None, :]
-    kperm = 16 * (j8 >> 2) + 4 * chunk + (j8 & 3)                               # [4][8] channel inside a 32-wide k step
+    kperm = (8 * chunk + j8) if natural else (16 * (j8 >> 2) + 4 * chunk + (j8 & 3))      # [4][8] channel inside a 32-wide k step
     n = ar(16)
 
     def cols(base, ntile):

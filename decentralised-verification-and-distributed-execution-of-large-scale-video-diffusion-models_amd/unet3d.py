@@ -79,6 +79,7 @@ class UNet3DConditionModel(nn.Module):
         self.fold_norm_proj_in = True  # GroupNorm -> proj_in as per-sample weights where the Linear is weights-stationary
         self.fuse_ff = True            # K8 where the width allows (False: LayerNorm, GEGLU GEMM, GEMM + residual)
         self.fuse_cross_attn = True    # K5 where the width and the text length allow (False: LayerNorm, q GEMM, flash attention, GEMM + residual)
+        self.fuse_proj_out = True      # (with K8) the transformer's proj_out + residual behind the feed-forward, in K8's kernel (False: a GEMM of its own)
         self.fuse_conv_gn = True       # K1 where it is faster — level 0 (False: GroupNorm apply pass + 3x3-conv GEMM; "always": wherever the shape allows, tests)
         self.fuse_tconv = True         # K3 where it is faster — level 0 (False: GroupNorm apply pass + temporal-conv GEMM; "always": wherever the shape allows, tests)
         self.spatial_v_rows = True     # spatial self-attention on one q|k|v projection, V as rows (False: round-2 form, A/B timing only)
@@ -163,6 +164,9 @@ class UNet3DConditionModel(nn.Module):
                 # K8: the feed-forward sub-block as one kernel, norm3 folded into its first projection (csrc/ff_fused.hip)
                 put(b + ".ff.k8", packing.pack_k8(sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"], sd[b + ".ff.net.2.weight"],
                                                  sd[b + ".ff.net.2.bias"], sd[b + ".norm3.weight"], sd[b + ".norm3.bias"]))
+            if sd[b + ".ff.net.2.weight"].shape[0] in packing.K8_WIDTHS and tuple(sd[prefix + ".proj_out.weight"].shape[:2]) == (sd[b + ".ff.net.2.weight"].shape[0],) * 2:
+                # K8's tail: proj_out + the transformer's residual in the feed-forward's kernel (csrc/ff_fused.hip, PO)
+                put(prefix + ".proj_out.k8p", packing.pack_k8_proj(packing.pack_conv1x1(sd[prefix + ".proj_out.weight"]), sd[prefix + ".proj_out.bias"]))
             if not temporal and sd[b + ".attn2.to_q.weight"].shape[0] in packing.K5_WIDTHS:
                 # K5: the cross-attention sub-block as one kernel, norm2 folded into its query projection (csrc/xattn.hip)
                 put(b + ".attn2.k5", packing.pack_k5(packing.pack_conv1x1(sd[b + ".attn2.to_q.weight"]), packing.pack_conv1x1(sd[b + ".attn2.to_out.0.weight"]),
@@ -440,6 +444,22 @@ class UNet3DConditionModel(nn.Module):
             del gg
         return out
 
+    def _ff_proj_out(self, b, p, t, x, M, xrows=None, ksplit_ok=True):
+        """The end of a transformer: `proj_out(t + ff(norm3(t))) + x`.  x has M rows, or `xrows` = M / 2 (a shared-prefix batch:
+        both halves of t pair with the same rows of x).  At level 0 ONE kernel (K8 with proj_out as its tail: the feed-forward's
+        output never reaches HBM); otherwise the feed-forward, then the projection GEMM with its residual."""
+        W = self.W
+        xrows = xrows or M
+        if self.fuse_ff and self.fuse_proj_out and b + ".ff.k8" in W and p + ".proj_out.k8p" in W and ops.ff_block_supported(t.shape[1]):
+            return ops.ff_block(t, W[b + ".ff.k8"], M=M, proj=(W[p + ".proj_out.k8p"], x, xrows))
+        t = self._ff(b, t, M, ksplit_ok=ksplit_ok)
+        if xrows == M:
+            return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
+        out = torch.empty((M, W[p + ".proj_out.weight"].shape[0]), dtype=torch.float16, device=t.device)
+        for i in range(M // xrows):     # two launches over half the rows each, the residual rows shared: no copy
+            ops.gemm(t[i * xrows:(i + 1) * xrows], W[p + ".proj_out.weight"], M=xrows, bias=W[p + ".proj_out.bias"], residual=x, out=out[i * xrows:(i + 1) * xrows])
+        return out
+
     def _norm_proj_in(self, p, x, n_samples, rows_per_sample, M, part=0):
         """`norm` -> `proj_in` at the entry of a transformer: GroupNorm (eps 1e-6, no activation) then a Linear.  Where the
         Linear runs on the weights-stationary kernels (levels 0 / 1, transformer_in) the norm is FOLDED into it — per-sample
@@ -527,14 +547,7 @@ class UNet3DConditionModel(nn.Module):
                     ops.cross_attn_block(t, W[b + ".attn2.k5"], kvb[i:i + 1], kv_len=self._text_len, n_items=1, rows_per_item=M, out=t2[i * M:(i + 1) * M])
             else:
                 t2 = ops.cross_attn_block(t, W[b + ".attn2.k5"], kvb, kv_len=self._text_len, n_items=nb, rows_per_item=M // nb)
-            t = self._ff(b, t2, M_out)
-            del t2
-            if not dup:
-                return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
-            out = torch.empty((M_out, C), dtype=torch.float16, device=x.device)
-            for i in range(nb):
-                ops.gemm(t[i * M:(i + 1) * M], W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x, out=out[i * M:(i + 1) * M])
-            return out
+            return self._ff_proj_out(b, p, t2, x, M_out, xrows=M)
         ln = ops.layernorm(t, W[b + ".norm2.weight"], W[b + ".norm2.bias"], M=M)
         q = ops.gemm(ln, W[b + ".attn2.to_q.weight"], M=M)
         del ln
@@ -548,19 +561,13 @@ class UNet3DConditionModel(nn.Module):
                 ops.gemm(o, W[b + ".attn2.to_out.0.weight"], M=M, bias=W[b + ".attn2.to_out.0.bias"], residual=t, out=t2[i * M:(i + 1) * M])
                 del o
             del q
-            t = self._ff(b, t2, M_out)
-            del t2
-            out = torch.empty((M_out, C), dtype=torch.float16, device=x.device)
-            for i in range(nb):
-                ops.gemm(t[i * M:(i + 1) * M], W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x, out=out[i * M:(i + 1) * M])
-            return out
+            return self._ff_proj_out(b, p, t2, x, M_out, xrows=M)
         o = ops.flash_attn(q, k, vt, n_seq=n_img, sq=S, skv=self._text_len, skv_pad=TEXT_PAD, heads=heads,
                            seq_per_kv=n_img // nb, scale=scale)
         del q
         t = ops.gemm(o, W[b + ".attn2.to_out.0.weight"], M=M, bias=W[b + ".attn2.to_out.0.bias"], residual=t)
         del o
-        t = self._ff(b, t, M)
-        return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
+        return self._ff_proj_out(b, p, t, x, M)
 
     def _temporal_transformer(self, p, x, B, F, S, heads, part=0, ksplit_ok=True):
         W, g = self.W, self.cfg.norm_num_groups
@@ -585,8 +592,7 @@ class UNet3DConditionModel(nn.Module):
             del qkv
             t = ops.gemm(o, W[f"{b}.{a}.to_out.0.weight"], M=M, bias=W[f"{b}.{a}.to_out.0.bias"], residual=t)
             del o
-        t = self._ff(b, t, M, ksplit_ok=ksplit_ok)
-        return ops.gemm(t, W[p + ".proj_out.weight"], M=M, bias=W[p + ".proj_out.bias"], residual=x)
+        return self._ff_proj_out(b, p, t, x, M, ksplit_ok=ksplit_ok)
 
     # ------------------------------------------------------------------------------------------
     def _time_embedding(self, timestep, B, device):

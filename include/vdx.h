@@ -224,6 +224,13 @@ int vdx_ff_block_supported(int inner);
 size_t vdx_ff_block_pack_bytes(int inner);
 int vdx_ff_block_f16(const void* t, int ldt, const void* packed, float eps, void* out, int ldo, int M, int inner,
                      vdx_stream_t stream);
+/* The same kernel with the transformer's `proj_out` and its residual behind the feed-forward (the sub-block's output never
+ * reaches HBM): out[r] = x[r % xrows] + W_p . (t[r] + ff(LayerNorm(t[r]))) + b_p.  x: the transformer's input rows, xrows = M, or
+ * M / 2 when both halves of the batch pair with the same rows of x (the CFG-shared prefix); proj_packed: vdx/packing.py
+ * pack_k8_proj (25 weight units, fp32 b_p; vdx_ff_block_proj_pack_bytes bytes).  out may alias neither t nor x. */
+size_t vdx_ff_block_proj_pack_bytes(int inner);
+int vdx_ff_block_proj_f16(const void* t, int ldt, const void* packed, float eps, const void* x, int ldx, int xrows,
+                          const void* proj_packed, void* out, int ldo, int M, int inner, vdx_stream_t stream);
 
 /* Temporal self-attention of TransformerTemporalModel: sequences run over the
  * F frames of one latent pixel.  qkv: fp16 rows [B*F*HW][ldqkv] = [q | k | v] each heads*64

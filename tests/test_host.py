@@ -128,7 +128,9 @@ def test_unet_weight_ingest_covers_every_diffusers_key():
     k8 = 10 * (300 * 4096 + 2 * (2 * 1280 + 320))
     # + the K5 blobs (csrc/xattn.hip): the five level-0 cross-attentions as 50 units of 4096 halfs + the two fp32 bias vectors
     k5 = 5 * (50 * 4096 + 2 * 2 * 320)
-    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7 + k8 + k5
+    # + K8's tail blobs (proj_out behind the feed-forward): the ten level-0 transformers, 25 units + the fp32 bias vector each
+    k8p = 10 * (25 * 4096 + 2 * 320)
+    assert m.num_parameters() == 1_411_233_860 + 60 * 2880 + 60 + 320 * 28 + k7 + k8 + k5 + k8p
     assert m.config.in_channels == 4
     sd["bogus.weight"] = torch.empty(1, device="meta")
     with pytest.raises(_lib.VdxError):

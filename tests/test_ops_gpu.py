@@ -1171,6 +1171,45 @@ def test_ff_block_fused(gpu, M):
     close(out, un.float().cpu(), tol=4e-3)
 
 
+@pytest.mark.parametrize("M,half_x", [(192, False), (1000, False), (2 * 9216, True), (300 * 192 + 40, False), (2 * 24 * 9216, True), (24 * 9216, False)])
+def test_ff_block_with_proj_out_fused(gpu, M, half_x):
+    """K8 with the transformer's proj_out + residual behind it (PO, round 5): out = x + W_p (t + ff(norm3(t))) + b_p in one
+    kernel, against the fp32 statement and against the kernels it replaces (K8, then the proj_out GEMM with its residual).
+    One tile, ragged tiles, many tiles per workgroup (the next tile's rows are fetched and normalised behind the tail: the
+    bits must repeat run to run), and `half_x`: both halves of the rows pair with the same rows of x (the shared prefix)."""
+    ops, _ = _ops()
+    from vdx import packing
+    g = torch.Generator(device=gpu).manual_seed(M)
+    inner = 320
+    r = lambda *sh, k=1.0: (torch.randn(*sh, device=gpu, generator=g) * k).half()      # noqa: E731
+    t = r(M, inner, k=1.5) + 0.3
+    xrows = M // 2 if half_x else M
+    x = r(xrows, inner)
+    gamma, beta = r(inner, k=0.2) + 1, r(inner, k=0.1)
+    w1, b1, w2, b2 = r(8 * inner, inner, k=0.06), r(8 * inner, k=0.1), r(inner, 4 * inner, k=0.03), r(inner, k=0.1)
+    wp, bp = r(inner, inner, k=0.05), r(inner, k=0.1)
+    blob = packing.pack_k8(w1, b1, w2, b2, gamma, beta)
+    tail = packing.pack_k8_proj(wp, bp)
+    out = ops.ff_block(t, blob, M=M, proj=(tail, x, xrows))
+    # the kernels it replaces
+    y = ops.ff_block(t, blob, M=M)
+    xx = torch.cat([x, x]) if half_x else x
+    un = ops.gemm(y, wp, M=M, bias=bp, residual=xx)
+    close(out, un.float().cpu(), tol=4e-3)
+    if M <= 20000:
+        f = lambda v: v.float().cpu()       # noqa: E731
+        ref = _ff_ref(f(t), f(gamma), f(beta), f(w1), f(b1), f(w2), f(b2)) @ f(wp).t() + f(bp) + f(xx)
+        close(out, ref, tol=5e-3)
+    for _ in range(3):
+        assert torch.equal(ops.ff_block(t, blob, M=M, proj=(tail, x, xrows)), out)
+    # rows are independent: a row range alone gives the same bits (tiles are 192 rows: a range that starts on a tile boundary)
+    if M > 384 and not half_x:
+        part = ops.ff_block(t[192:], blob, M=M - 192, proj=(tail, x[192:], M - 192))
+        assert torch.equal(part, out[192:])
+    # the plain kernel is unchanged by the shared template
+    assert torch.equal(ops.ff_block(t, blob, M=M), y)
+
+
 def test_ff_block_large_mean_and_outliers(gpu):
     """Rows with a large common offset (LayerNorm statistics) and gate values far outside the polynomial's interval."""
     ops, _ = _ops()
