@@ -15,7 +15,9 @@ GUARDED = (
     "gemm_kernel<256, 320, 4, 2, 0, false, false, 0>",     # tiled Linear
     "flash_attn_kernel<2, false, true>",                   # spatial self-attention
     "tattn2_kernel<320, 24>",                              # K7, second design
-    "ff_fused_kernel<320>",                                # K8
+    "ff_fused_kernel<320>",                                # K8 (rounds 3-4)
+    "ff_fused_kernel<320, true>",                          # K8 with proj_out as its tail (round 5)
+    "xattn_kernel<320>",                                   # K5 (round 5)
     "conv3x3_gn_kernel",                                   # K1 (level-0 3x3 convolutions, round 4)
     "tconv_gn_kernel<12>",                                 # K3 (level-0 temporal convolutions at 24 frames, round 4)
 )
