@@ -23,6 +23,6 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output
 python tools/pmc_summary.py $OUT/pmc/fetch $OUT/pmc/write $OUT/pmc/mfma --json $OUT/pmc_current.json > $OUT/pmc_summary.md
 rm -rf $OUT/stats $OUT/stats_dup $OUT/pmc
 echo "== bench (default flags)"; python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json
-echo "== tools"; { echo "## tools/block_profile.py"; python tools/block_profile.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/attn_bench.py"; python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/k7_bench.py"; python tools/k7_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/gemm_bench.py"; python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids; } > $OUT/tools.txt
+echo "== tools"; { echo "## tools/block_profile.py"; python tools/block_profile.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/attn_bench.py"; python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/k7_bench.py"; python tools/k7_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/gemm_bench.py"; python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/k5_bench.py"; python tools/k5_bench.py 2>&1 | grep -v amdgpu.ids; echo; echo "## tools/k8p_bench.py"; python tools/k8p_bench.py 2>&1 | grep -v amdgpu.ids; } > $OUT/tools.txt
 tail -5 $OUT/tools.txt
 if [ $GUARD_RC -ne 0 ]; then echo "round_profile: perf_guard FAILED (see $OUT/perf_guard.txt)"; exit 1; fi
