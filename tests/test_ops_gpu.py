@@ -912,6 +912,23 @@ def test_cross_attn_block_fused(gpu, n_items, rows, kv_len):
     assert torch.equal(wide_out[:, :inner], out) and bool((wide_out[:, inner:] == 7.0).all())
 
 
+def test_cross_attn_block_run_to_run_bits_at_full_size(gpu):
+    """Nine tiles per workgroup, every wave's counted waits under load, the key / value units of two items streaming through
+    the ring beside the weights: the bits must repeat (a wait that counts more vector-memory instructions than the ISA holds
+    would let a unit be read before it has landed — the failure shows as a run-to-run difference at full size only)."""
+    ops, packing = _ops()
+    inner, pad, kv_len, n_items, rows = 320, 128, 77, 2, 24 * 9216
+    g = torch.Generator(device=gpu).manual_seed(9)
+    r = lambda *sh, k=1.0: (torch.randn(*sh, device=gpu, generator=g) * k).half()      # noqa: E731
+    blob = packing.pack_k5(r(inner, inner, k=0.09), r(inner, inner, k=0.05), r(inner, k=0.2) + 1, r(inner, k=0.1), r(inner, k=0.1), 0.125)
+    kvb = packing.pack_k5_kv(r(n_items * pad, inner), r(inner, n_items * pad), n_items, pad)
+    t = r(n_items * rows, inner, k=1.5)
+    first = ops.cross_attn_block(t, blob, kvb, kv_len=kv_len, n_items=n_items, rows_per_item=rows).clone()
+    assert bool(torch.isfinite(first.float()).all())
+    for _ in range(6):
+        assert torch.equal(ops.cross_attn_block(t, blob, kvb, kv_len=kv_len, n_items=n_items, rows_per_item=rows), first)
+
+
 @pytest.mark.parametrize("Fr,HW", [(24, 1100), (16, 37), (12, 700)])
 def test_temporal_attn_block2_batch_invariant(gpu, Fr, HW):
     """A sample's result has the same bits wherever it sits in the batch and whatever else is in it: tiles are aligned
