@@ -462,7 +462,7 @@ def main():
             shapes = {}
             for name, flops, e0, e1, mnk in prof:
                 ms_ = e0.elapsed_time(e1)
-                for d_, k_ in ((agg, name), (shapes, (name.split("_")[0][:5] + " " + name.split("<")[1][:14],) + mnk)):
+                for d_, k_ in ((agg, name), (shapes, (name.split("_")[0][:5] + " " + (name.split("<")[1][:14] if "<" in name else name[:14]),) + mnk)):
                     a = d_.setdefault(k_, [0.0, 0.0, 0])
                     a[0] += flops
                     a[1] += ms_

@@ -682,8 +682,16 @@ def cross_attn_block(t, packed, kv_packed, *, kv_len, n_items, rows_per_item, ep
         raise VdxError("cross_attn_block: out too small")
     if out.data_ptr() == t.data_ptr():
         raise VdxError("cross_attn_block: out may not alias t")
+    rec = PROFILE is not None and _profiled(f"xattn_kernel<{inner}>")
+    if rec:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(lib.vdx_cross_attn_block_f16(_p(t, "t"), ldt, _p(packed, "packed"), _p(kv_packed, "kv_packed"), int(kv_len), float(eps),
                                             _p(out, "out"), ldo, n_items, rows_per_item, inner, _stream()), "vdx_cross_attn_block_f16")
+    if rec:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        PROFILE.append((f"xattn_kernel<{inner}>", 2.0 * M * (2 * inner * inner + 2 * kv_len * inner), ev0, ev1, (M, inner, 2 * inner + 2 * kv_len)))
     return out
 
 
