@@ -89,28 +89,122 @@ def shared_prefix_tflop(frames: int, hw: int = 72 * 128) -> float:
     return 2.0 * macs * frames * hw / 1e12
 
 
-def cpu_baseline(frames: int, threads: int):
+def cpu_baseline_inputs(frames: int):
+    """The bounded sample's inputs (fp16-rounded, so the oracle and the HIP forward see the same numbers): ONE latent for both
+    CFG items — what `fsdp_chunked_coherent.py:133` builds — and two different text embeddings."""
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 4, frames, 72, 128, generator=g).half()
+    e = torch.randn(2, 77, 1024, generator=g).half()
+    return lat, e
+
+
+def cpu_baseline(frames: int, threads: int, state_dict=None, hip_out=None):
     """Oracle (fp32 PyTorch-CPU restatement, kind "port") timed on this host on a bounded sample:
     one CFG UNet forward with XL-shaped weights at `frames` frames @ 576x1024; FLOPs are linear in
-    the frame count, so the 24-frame rate is sample_time * 24/frames."""
+    the frame count, so the 24-frame rate is sample_time * 24/frames.
+    `state_dict` (the table the HIP UNet of this process was loaded from) + `hip_out` (its output on
+    `cpu_baseline_inputs(frames)`): the oracle then runs on the SAME weights and inputs and the line carries
+    `rel_l2_vs_hip` — a parity number at the benchmark's own spatial extent from every driver run.
+    The oracle is the checker here, never the thing measured as the product."""
     from oracle.unet3d_ref import UNet3DConditionModelRef, UNet3DConfig
     torch.set_num_threads(threads)
     with torch.device("meta"):
         m = UNet3DConditionModelRef(UNet3DConfig.zeroscope())
     m = m.to_empty(device="cpu").eval()
     with torch.no_grad():
-        for p in m.parameters():
-            p.normal_(0.0, 0.02)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, frames, 72, 128, generator=g)
-    e = torch.randn(2, 77, 1024, generator=g)
+        if state_dict is not None:
+            m.load_state_dict({k: v.float().cpu() for k, v in state_dict.items()})
+        else:
+            for p in m.parameters():
+                p.normal_(0.0, 0.02)
+    lat, e = cpu_baseline_inputs(frames)
+    x = torch.cat([lat, lat]).float()
     t0 = time.time()
     with torch.no_grad():
-        m(x, torch.tensor(981), e)
+        y = m(x, torch.tensor(981), e.float()).sample
     dt = time.time() - t0
-    return {"value": round(1.0 / (dt * 24.0 / frames), 6), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32 torch-CPU UNet3D, XL widths, 1 CFG forward at {frames} of 24 frames @576x1024 "
-                      f"({dt:.1f} s), scaled x{24 / frames:g} to the 24-frame step"}
+    out = {"value": round(1.0 / (dt * 24.0 / frames), 6), "unit": "steps/s", "cores": threads, "kind": "port",
+           "sample": f"oracle fp32 torch-CPU UNet3D, XL widths, 1 CFG forward at {frames} of 24 frames @576x1024 "
+                     f"({dt:.1f} s), scaled x{24 / frames:g} to the 24-frame step"}
+    if hip_out is not None:
+        out["rel_l2_vs_hip"] = round(float((hip_out.double() - y.double()).norm() / y.double().norm()), 6)
+        out["rel_l2_vs_hip_note"] = (f"HIP fp16 forward (shared CFG prefix) vs this fp32 oracle forward: same seeded weights, same inputs, "
+                                     f"(2,4,{frames},72,128); test bound 4e-3 (tests/test_full_extent_gpu.py)")
+    return out
+
+
+def box_probe(dev):
+    """What THIS box gives a fixed instruction stream and a fixed copy, measured in this process before the warm-up and outside
+    the timed region (~0.2 s): the boxes of the pool differ by several per cent as a whole (BENCH_r05 ran every kernel 7-9 %
+    slower than the builder's box on unchanged sources), and a line without this cannot tell a slower part from a slower build.
+      mfma_probe_tflops  `vdx_probe_mfma_f16`: dense v_mfma_f32_32x32x16_f16, two waves per SIMD, per-lane operands, every CU
+      hbm_probe_gbs      1 GiB device-to-device copy (read + write bytes / time, median of 3)
+    `tools/perf_guard.py` and a reader normalise `ms_per_step` by mfma_probe_tflops (the step is MFMA-bound by arithmetic)."""
+    from vdx import ops
+    out = {"mfma_probe_tflops": round(ops.probe_mfma(dev), 1)}
+    n = 1 << 30
+    a = torch.zeros(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    ts_ = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ts_.append(e0.elapsed_time(e1))
+    out["hbm_probe_gbs"] = round(2 * n / (sorted(ts_)[1] * 1e-3) / 1e9, 1)
+    del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
+class SclkSampler:
+    """Mean shader clock over the timed steps, read from amdsmi by a thread every 20 ms (host only: no GPU work, no
+    effect on the stream).  None with a reason where amdsmi cannot be used (not every box lets an ordinary user in)."""
+
+    def __init__(self, index):
+        self.samples, self.err, self._stop, self._thr = [], None, False, None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self._smi, self._h = amdsmi, hs[index if index < len(hs) else 0]
+            self._read()                    # fail here, not in the thread
+        except Exception as e:              # noqa: BLE001 — a diagnostic: never fail the bench line for it
+            self.err = f"{type(e).__name__}: {e}"[:160]
+
+    def _read(self):
+        d = self._smi.amdsmi_get_clock_info(self._h, self._smi.AmdSmiClkType.GFX)
+        v = d.get("clk", d.get("cur_clk"))
+        return float(v) if isinstance(v, (int, float)) else None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+            except Exception as e:          # noqa: BLE001
+                self.err = f"{type(e).__name__}: {e}"[:160]
+                return
+            time.sleep(0.02)
+
+    def start(self):
+        if self.err is None:
+            import threading
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+        if self.samples:
+            return {"sclk_mhz_mean": round(sum(self.samples) / len(self.samples), 1), "sclk_mhz_min": min(self.samples),
+                    "sclk_mhz_max": max(self.samples), "sclk_samples": len(self.samples)}
+        return {"sclk_mhz_mean": None, "sclk_note": self.err or "no samples"}
 
 
 def copy_activity_of_a_step(step, i, lats):
@@ -152,6 +246,8 @@ def self_launch(argv, n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL and the peer-mapped shard arenas need here
     env.setdefault("OMP_NUM_THREADS", "1")
+    from vdx.shard import configure_rccl_env
+    configure_rccl_env(env)
     r = subprocess.run(self_launch_command(argv, n, port), stdout=subprocess.PIPE, text=True, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{") and '"metric"' in ln]
     if lines:
@@ -201,6 +297,13 @@ def main():
                     help="skip the second timing of the same steps with the CFG-shared prefix off (`ms_per_step_full_duplicate`)")
     ap.add_argument("--rehearse-copies", action="store_true",
                     help="with --rehearse-dist --as-world N on one GPU: issue every parameter gather as N copies (the host call count of a node)")
+    ap.add_argument("--hog", type=int, default=0,
+                    help="with --rehearse-dist --as-world N: beside every parameter gather the side stream holds this many CUs "
+                         "(workgroups of 256 threads with 64 KB of LDS that touch no memory) for the time a ring all-gather of the "
+                         "group's remote bytes takes at --hog-gbs: what RCCL's channel kernels take from the step's persistent grids")
+    ap.add_argument("--hog-gbs", type=float, default=100.0, help="modelled all-gather rate per GPU for --hog (GB/s)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="rehearsal: CUs every persistent grid leaves free (vdx_set_reserved_cus); default = what the store chose")
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP events around EVERY matrix kernel (the per-family table `gemm_kernels`): costs ~2.6 ms per step; the "
                          "default times only the two candidates for the dominant kernel (3x3-conv GEMM, spatial flash attention)")
@@ -243,6 +346,8 @@ def main():
         if args.rehearse_dist:
             os.environ["VDX_SHARD_FORCE_COLLECTIVE"] = "1"
         if args.backend == "nccl":
+            from vdx.shard import configure_rccl_env
+            configure_rccl_env()          # cap RCCL's channels (= CUs held beside the step) before the communicator exists
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -272,6 +377,14 @@ def main():
             # a gather = as_world LOCAL copies: the host-side call count of a node.  (On one GPU every one of them is a
             # blit kernel on the GPU that is computing; on a node 7 of 8 are remote pulls.  An upper bound of the cost.)
             unet.W.rehearse_copies = args.as_world
+        if args.hog:
+            if not (args.rehearse_dist and args.as_world > 1 and world == 1):
+                raise SystemExit("--hog is a one-GPU rehearsal aid: use it with --rehearse-dist --as-world N")
+            unet.W.rehearse_hog = (args.hog, 64 << 10, args.hog_gbs, args.as_world)
+        if args.reserve_cus >= 0:
+            if not args.rehearse_dist:
+                raise SystemExit("--reserve-cus is a rehearsal aid (the store sets the reserve itself for world > 1)")
+            ops.set_reserved_cus(args.reserve_cus)
     if args.no_shared_prefix:
         unet.share_cfg_prefix = False
     if args.ff_block_mb:
@@ -316,9 +429,11 @@ def main():
             out.append(sched.step_cfg(noise, t, lat, 7.5))
         return out
 
+    box = box_probe(dev) if rank == 0 else {}
     for i in range(args.warmup):
         lats = step(i, lats)
     torch.cuda.reset_peak_memory_stats()
+    sclk = SclkSampler(local) if rank == 0 else None
 
     def fence():
         torch.cuda.synchronize()
@@ -334,11 +449,15 @@ def main():
     store = unet.W if hasattr(unet.W, "transport") else None
     g0, h0 = (store.gathers, store.gather_host_s) if store is not None else (0, 0.0)
     fence()
+    if sclk is not None:
+        sclk.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         lats = step(args.warmup + i, lats)
     fence()
     dt = time.perf_counter() - t0
+    if sclk is not None:
+        box.update(sclk.stop())
     g1, h1 = (store.gathers, store.gather_host_s) if store is not None else (0, 0.0)
     ops.PROFILE = None
     finite = all(bool(torch.isfinite(lat.float()).all()) for lat in lats)
@@ -392,18 +511,23 @@ def main():
             # per-device peak against the monolithic single-GPU peak at the SAME total frame count
             # (profiles/monolithic_peaks.json, measured by tools/mem_profile.py --frames T); north star: <= 0.15 at N = 8
             "peak_hbm_frac_of_monolithic": round(peak_gb / mono, 4) if mono else None,
-            # reference-equivalent FLOPs: what the reference's step computes for these frames (both CFG items in every block)
-            "path_tflops_per_gpu": round(tf_step * args.steps / dt, 2),
-            "path_mfma_frac": round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4),
             "output_finite": finite,
+            "box": box,
         }
-        # EXECUTED FLOPs: the shared prefix computes its blocks for one item, not two
+        # EXECUTED FLOPs: the shared prefix computes its blocks for one item, not two.  `path_tflops_per_gpu` / `path_mfma_frac`
+        # — the fields tracked since round 1 — carry the EXECUTED work since round 6 (on the reference-equivalent
+        # count a removed duplicate read as a utilisation gain); the reference-equivalent figures keep their own names.
         saved = sum(shared_prefix_tflop(e_ - s_, H * W) for s_, e_ in ranges) if shared_on else 0.0
         out["cfg_shared_prefix"] = shared_on
         out["tflop_per_step_reference_equivalent"] = round(tf_step, 2)
         out["tflop_per_step_executed"] = round(tf_step - saved, 2)
-        out["path_tflops_executed_per_gpu"] = round((tf_step - saved) * args.steps / dt, 2)
-        out["path_mfma_frac_executed"] = round((tf_step - saved) * args.steps / dt / PEAK_MFMA_TFLOPS, 4)
+        out["path_tflops_per_gpu"] = out["path_tflops_executed_per_gpu"] = round((tf_step - saved) * args.steps / dt, 2)
+        out["path_mfma_frac"] = out["path_mfma_frac_executed"] = round((tf_step - saved) * args.steps / dt / PEAK_MFMA_TFLOPS, 4)
+        out["path_tflops_reference_equivalent_per_gpu"] = round(tf_step * args.steps / dt, 2)
+        out["path_mfma_frac_reference_equivalent"] = round(tf_step * args.steps / dt / PEAK_MFMA_TFLOPS, 4)
+        if box.get("mfma_probe_tflops"):
+            # the step against what THIS box's matrix pipe sustains on the probe stream: comparable across boxes
+            out["box"]["step_tflops_over_probe"] = round((tf_step - saved) * args.steps / dt / box["mfma_probe_tflops"], 4)
         if dt_dup > 0:
             out["ms_per_step_full_duplicate"] = round(1e3 * dt_dup / args.steps, 3)
             out["path_mfma_frac_full_duplicate"] = round(tf_step * args.steps / dt_dup / PEAK_MFMA_TFLOPS, 4)
@@ -415,6 +539,11 @@ def main():
             out["shard_gathers_per_step"] = round((g1 - g0) / args.steps, 1)
             out["shard_copies_per_gather"] = (store.rehearse_copies or store.world) if store.transport == "peer" else None
             out["shard_gather_host_ms_per_step"] = round(1e3 * (h1 - h0) / args.steps, 3)
+            out["persistent_grid_reserved_cus"] = ops.reserved_cus()
+            out["rccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+            if store.rehearse_hog is not None:
+                out["rehearse_hog"] = {"cus_held": store.rehearse_hog[0], "lds_bytes": store.rehearse_hog[1],
+                                       "modelled_allgather_gbs": store.rehearse_hog[2], "as_world": store.rehearse_hog[3]}
             if args.profile_all:
                 out.update(copy_activity_of_a_step(step, args.warmup + args.steps, lats))
         if args.rehearsal or args.rehearse_dist:
@@ -424,6 +553,7 @@ def main():
             # per cent): N ranks each denoise a `my_frames`-frame window with sharded weights while one GPU alone takes
             # t24 for the 24-frame clip; useful frames per step: N x 12 against 24.  The monolithic step
             # is timed here on a second, resident copy of the same weights, after the rehearsal's memory peak was read.
+            ops.set_reserved_cus(0)                               # one GPU alone runs no collective: full grids
             unet24 = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, 1234, dev), device=dev)
             lat24 = seeded_noise((1, 4, 24, H, W), sched.init_noise_sigma, dev)
 
@@ -494,10 +624,17 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None, "kernel": "whole step"}
         if world == 1 and args.cpu_frames > 0 and not args.rehearse_dist and cname == "cfg2":
+            hip_y = sd_cpu = None
+            if not args.peaked:
+                # the HIP forward the oracle sample is compared with: this process's UNet on the sample's inputs
+                lat_s, e_s = cpu_baseline_inputs(args.cpu_frames)
+                unet.share_cfg_prefix = True
+                hip_y = unet(ops.cfg_input(lat_s.to(dev), None, 0.0), 981, encoder_hidden_states=e_s.to(dev)).sample.float().cpu()
+                sd_cpu = synthetic_state_dict(cfg, 1234, dev)      # the table `unet` was loaded from (same generator, same seed)
             del unet
             torch.cuda.empty_cache()
             ncpu = min(len(os.sched_getaffinity(0)), 16)      # the 1-GPU box's CPU share
-            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, ncpu)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, ncpu, sd_cpu, hip_y)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_mode:
         dist.barrier()

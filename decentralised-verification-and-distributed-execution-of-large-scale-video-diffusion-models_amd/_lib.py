@@ -87,6 +87,11 @@ SIGNATURES = {
     "vdx_ipc_open": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vdx_ipc_close": (_i, [_vp, _sz]),
     "vdx_peer_gather": (_i, [_vp, C.POINTER(_vp), _i, _sz, _vp]),
+    "vdx_set_reserved_cus": (_i, [_i]),
+    "vdx_reserved_cus": (_i, []),
+    "vdx_persistent_grid_cus": (_i, []),
+    "vdx_probe_mfma_f16": (_i, [_vp, _sz, _i, C.POINTER(C.c_double), _vp]),
+    "vdx_probe_occupancy_hog": (_i, [_i, _i, _i, _vp]),
     "vdx_cfg_input_f16": (_i, [_vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "vdx_cfg_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),
     "vdx_ddim_step_f16": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _sz, _vp]),

@@ -276,3 +276,63 @@ extern "C" int vdx_rows_to_u8_frames(const void* rows, int ld, size_t n_pixels, 
                        (const f16*)rows, ld, n_pixels, (unsigned char*)out_u8);
     return vdx_launch_status("vdx_rows_to_u8_frames");
 }
+
+// ---- box probes (bench.py's `box` object, the distributed rehearsal's occupancy hog): NOT on the denoising path ------------
+// The boxes of a pool differ by several per cent as a whole (clock held under a dense MFMA stream, HBM speed).  A bench line
+// that carries the rate of a FIXED instruction stream measured in the same process lets a reader tell a slower part from a
+// slower build.  The probe is the stream every matrix kernel of this library is made of: back-to-back
+// v_mfma_f32_32x32x16_f16 on eight accumulators per wave, two waves per SIMD, operands that differ per lane and rotate per
+// issue (a constant-operand stream clocks ~40 % higher than real data: MI355X_MICROARCH.md, tools/micro/mfma_peak.hip).
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters) {
+    f16x8 a[4], b[4];
+    unsigned s = (threadIdx.x + 1u) * 2654435761u ^ (blockIdx.x * 40503u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s = s * 1664525u + 1013904223u;
+            a[r][e] = (f16)(((int)(s >> 16 & 1023) - 512) * (1.0f / 512.0f));
+            s = s * 1664525u + 1013904223u;
+            b[r][e] = (f16)(((int)(s >> 16 & 1023) - 512) * (1.0f / 8192.0f));
+        }
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[(i + (i >> 2)) & 3], acc[i], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][15];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = t;
+}
+// FLOPs of one launch: blocks x 4 waves x iters x 8 MFMAs x 2*32*32*16
+extern "C" int vdx_probe_mfma_f16(float* out, size_t out_floats, int iters, double* flops, vdx_stream_t stream) {
+    const int blocks = 2 * vdx_num_cus();
+    VDX_CHECK(out && out_floats >= (size_t)blocks * 256 && iters > 0 && iters <= (1 << 22), "probe_mfma: needs %d floats of scratch, 0 < iters <= 4M", blocks * 256);
+    if (flops) *flops = (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+    return vdx_launch_status("vdx_probe_mfma_f16");
+}
+
+// Occupancy hog: `blocks` workgroups of 256 threads that each hold `lds_bytes` of a CU's LDS for `micros` microseconds and
+// touch no memory — what a CU held by a collective's channel kernel looks like to an exact-fit persistent grid
+// (`bench.py --rehearse-dist --hog R`: DESIGN §5).  The wait is on the constant 100 MHz wall clock with s_sleep between
+// polls (no issue slots taken from a co-resident wave); every wave reaches the exit condition.
+__global__ __launch_bounds__(256) void occupancy_hog_kernel(long long ticks) {
+    extern __shared__ char hog_lds[];
+    if (ticks < 0) hog_lds[threadIdx.x] = 1;          // keeps the allocation alive; never taken
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int vdx_probe_occupancy_hog(int blocks, int lds_bytes, int micros, vdx_stream_t stream) {
+    VDX_CHECK(blocks > 0 && blocks <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && micros > 0 && micros <= 200000,
+              "probe_occupancy_hog: blocks 1..256, lds 0..160 KB, 1..200000 us");
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)occupancy_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc != hipSuccess) return vdx_fail("probe_occupancy_hog: cannot reserve LDS");
+    hipLaunchKernelGGL(occupancy_hog_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (long long)micros * 100);
+    return vdx_launch_status("vdx_probe_occupancy_hog");
+}

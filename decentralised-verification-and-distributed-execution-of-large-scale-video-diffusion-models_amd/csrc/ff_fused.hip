@@ -705,7 +705,7 @@ static int ff_block_launch(const void* t, int ldt, const void* packed, float eps
         return a != hipSuccess ? a : b;
     }();
     if (attr_rc != hipSuccess) return vdx_fail("ff_block: cannot reserve %d bytes of LDS", lds);
-    const int ncu = vdx_num_cus();
+    const int ncu = vdx_grid_cus();
     const int rounds = (p.ntiles + ncu - 1) / ncu;
     const int grid = (p.ntiles + rounds - 1) / rounds;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);

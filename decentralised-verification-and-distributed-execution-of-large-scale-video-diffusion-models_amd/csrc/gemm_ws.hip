@@ -45,6 +45,7 @@ struct WsP {
     int nt;         // column panels
     int groups;     // row groups (256 / nt): blocks of a group walk the same chunks
     int nch;        // chunks in all (M / ROWS)
+    int per_xcd;    // blocks per XCD (grid / 8): 32 when the grid fills the 256 CUs
 };
 
 // WSET: one weight set per p.wset_rows rows (a GroupNorm folded into this Linear, norm.hip gn_fold_kernel): the register
@@ -239,7 +240,7 @@ struct Ws {
         fq = lane >> 4;
         // block -> (row group, panel): blocks b and b+8 share an XCD, so linear slot (b&7)*32 + (b>>3)
         // keeps the panels of one row group next to each other on one XCD (L2 hits on their common chunks)
-        const int slot = (blockIdx.x & 7) * 32 + (blockIdx.x >> 3);
+        const int slot = (blockIdx.x & 7) * q.per_xcd + (blockIdx.x >> 3);
         const int group = slot / q.nt, panel = slot - group * q.nt;
         if (group >= q.groups) return;
         c0 = (int)((long long)q.nch * group / q.groups);
@@ -320,9 +321,12 @@ int launch_ws(const GemmP& p, hipStream_t st) {
     WsP q;
     q.g = p;
     q.nt = (p.N + 32 * NW - 1) / (32 * NW);
-    q.groups = 256 / q.nt;               // 256 CUs: one block per CU
+    int grid = vdx_grid_cus() < 256 ? vdx_grid_cus() : 256;       // one block per CU (minus the reserve); a multiple of 8
+    if (grid < q.nt) grid = (q.nt + 7) & ~7;                      // (a reserve so large that one row group no longer fits)
+    q.groups = grid / q.nt;
     q.nch = p.M / ROWS;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, st, q);
+    q.per_xcd = grid / 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, q);
     return vdx_launch_status("vdx_gemm_f16 (weights-stationary)");
 }
 

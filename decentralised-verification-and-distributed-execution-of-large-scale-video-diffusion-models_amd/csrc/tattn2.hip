@@ -831,7 +831,7 @@ extern "C" int vdx_temporal_attn_block2_f16(const void* t, int ldt, const void* 
     }();
     if (attr_rc != hipSuccess) return vdx_fail("temporal_attn_block2: cannot reserve %d bytes of LDS", lds);
     // persistent grid: every workgroup walks the same number of tiles (+-1), one workgroup per CU at most
-    const int ncu = vdx_num_cus();
+    const int ncu = vdx_grid_cus();
     const int rounds = (p.ntiles + ncu - 1) / ncu;
     const int grid = (p.ntiles + rounds - 1) / rounds;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);

@@ -45,6 +45,16 @@ static inline int vdx_num_cus() {
     return n;
 }
 
+// Compute units a PERSISTENT grid may fill: all of them, minus the reserve the shard store asks for when parameter gathers
+// run beside the step (RCCL's channel kernels each hold a CU: an exact-fit grid of 256 blocks would leave the displaced
+// blocks to a second round).  A multiple of 8 (the XCD-aware block maps).  Results never depend on it: every persistent
+// kernel computes a tile's bits from the tile alone.  `vdx_set_reserved_cus` (common.hip), include/vdx.h.
+extern int g_vdx_reserved_cus;
+static inline int vdx_grid_cus() {
+    int n = (vdx_num_cus() - g_vdx_reserved_cus) & ~7;
+    return n < 8 ? 8 : n;
+}
+
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below fp16

@@ -658,7 +658,7 @@ extern "C" int vdx_cross_attn_block_f16(const void* t, int ldt, const void* pack
     constexpr int lds = T::XB + T::NU * T::UB;
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)xattn_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr_rc != hipSuccess) return vdx_fail("cross_attn_block: cannot reserve %d bytes of LDS", lds);
-    const int ncu = vdx_num_cus();
+    const int ncu = vdx_grid_cus();
     const int rounds = (p.ntiles + ncu - 1) / ncu;
     const int grid = (p.ntiles + rounds - 1) / rounds;
     hipLaunchKernelGGL(xattn_kernel<320>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);

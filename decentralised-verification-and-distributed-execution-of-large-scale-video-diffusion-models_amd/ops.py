@@ -807,3 +807,46 @@ def blend_finalize(full, weight):
                                           _p(out, "out", torch.float32), Cc, T, H * W, _stream()),
                "vdx_blend_finalize_f32")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Persistent-grid reserve and box probes (include/vdx.h, last section): not on the denoising path
+def set_reserved_cus(n: int) -> int:
+    """Leave `n` compute units free in every persistent grid (weights-stationary GEMMs, K5 / K7 / K8) for the channel kernels
+    of a collective that runs beside the step (vdx/shard.py sets it for world > 1).  Results do not depend on it.
+    Returns the CU count the persistent grids now fill."""
+    lib = _lib.load()
+    _lib.check(lib.vdx_set_reserved_cus(int(n)), "vdx_set_reserved_cus")
+    return lib.vdx_persistent_grid_cus()
+
+
+def reserved_cus() -> int:
+    return _lib.load().vdx_reserved_cus()
+
+
+def probe_mfma(device, iters: int = 4000, repeats: int = 3) -> float:
+    """Sustained TFLOP/s of a FIXED dense fp16 MFMA stream on this part, in this process (`vdx_probe_mfma_f16`): what the
+    box gives the instruction every matrix kernel of the library is made of.  Median of `repeats` timed launches after one
+    warm-up launch (~20 ms each at the default `iters`)."""
+    lib = _lib.load()
+    n = 2 * torch.cuda.get_device_properties(device).multi_processor_count * 256
+    scratch = torch.empty(n, dtype=torch.float32, device=device)
+    flops = C.c_double(0.0)
+    times = []
+    for r in range(repeats + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.vdx_probe_mfma_f16(_p(scratch, "scratch", torch.float32), n, iters, C.byref(flops), _stream()), "vdx_probe_mfma_f16")
+        e1.record()
+        e1.synchronize()
+        if r:
+            times.append(e0.elapsed_time(e1))
+    times.sort()
+    return flops.value / (times[len(times) // 2] * 1e-3) / 1e12
+
+
+def occupancy_hog(blocks: int, lds_bytes: int, micros: int, stream=None) -> None:
+    """Enqueue `blocks` workgroups that hold `lds_bytes` of a CU's LDS each for `micros` us and touch no memory — a stand-in
+    for the CUs a collective's channel kernels hold (one-GPU rehearsal of the distributed path, bench.py --hog)."""
+    st = stream.cuda_stream if stream is not None else _stream()
+    _lib.check(_lib.load().vdx_probe_occupancy_hog(int(blocks), int(lds_bytes), int(micros), st), "vdx_probe_occupancy_hog")

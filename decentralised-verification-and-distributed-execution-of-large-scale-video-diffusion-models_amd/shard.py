@@ -39,6 +39,34 @@ import torch.distributed as dist
 
 ALIGN = 64          # elements: keeps every view 128-byte aligned
 
+# RCCL's all-gather runs as `nchannels` workgroups, each holding a compute unit for the duration of the collective.  The
+# weights-stationary GEMMs and K5 / K7 / K8 launch ONE workgroup per CU with up to 160 KB of LDS: beside a gather an exact-fit
+# grid leaves its displaced workgroups to a second round (up to 2x on those launches).  So for world > 1 the store (a) caps
+# RCCL at RCCL_CHANNELS channels (`configure_rccl_env`, before the communicator exists) and (b) makes every persistent grid
+# leave as many CUs free (`vdx_set_reserved_cus`; results do not depend on it).  The number comes from the one-GPU
+# occupancy-hog rehearsal, profiles/r06_rccl_contention.md; VDX_RESERVED_CUS / NCCL_MAX_NCHANNELS override.
+RCCL_CHANNELS = 16
+
+
+def configure_rccl_env(env=None):
+    """Cap RCCL's channel count (= the CUs its kernels hold) unless the caller already chose: call BEFORE
+    `init_process_group` / the first collective (bench.py does; the launcher's environment is inherited by the ranks)."""
+    env = os.environ if env is None else env
+    env.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_CHANNELS))
+    env.setdefault("NCCL_MIN_NCHANNELS", str(min(RCCL_CHANNELS, 4)))
+    return env
+
+
+def reserved_cus_for(world: int, transport: str) -> int:
+    """CUs the persistent grids leave to the collective's channel kernels: none for a world of one or for copy-engine
+    pulls (peer transport), else VDX_RESERVED_CUS or the RCCL channel cap in force."""
+    if world <= 1 or transport != "collective":
+        return 0
+    v = os.environ.get("VDX_RESERVED_CUS")
+    if v is not None:
+        return int(v)
+    return int(os.environ.get("NCCL_MAX_NCHANNELS", RCCL_CHANNELS))
+
 
 def _FORCE_COLLECTIVE():
     """Rehearsal switch: go through the gather transport even for a world of 1 (bench.py --rehearse-dist)."""
@@ -148,6 +176,12 @@ class ShardedStore:
             raise ValueError(f"unknown shard transport {want!r}")
         if want == "peer" and self._cuda and comm is None and (world > 1 or _FORCE_COLLECTIVE() or transport == "peer"):
             self._setup_peer()
+        self.rehearse_hog = None               # (blocks, lds bytes, modelled GB/s, as_world): one-GPU rehearsal of the CUs RCCL holds
+        self.reserved_cus = 0
+        if self._cuda:
+            from . import ops
+            self.reserved_cus = reserved_cus_for(world, self.transport)
+            ops.set_reserved_cus(self.reserved_cus)
 
     # ---- peer transport -----------------------------------------------------------------------
     def _setup_peer(self):
@@ -297,6 +331,13 @@ class ShardedStore:
                 if self._released[slot] is not None:
                     self._side.wait_event(self._released[slot])     # old contents no longer needed
                 run()
+                if self.rehearse_hog is not None:
+                    # one-GPU rehearsal: hold `blocks` CUs for as long as a ring all-gather of this group's REMOTE bytes
+                    # would take at the modelled rate — what the step's persistent grids see beside a real collective
+                    from . import ops
+                    blocks, lds, gbs, as_world = self.rehearse_hog
+                    remote = n * out.element_size() * (as_world - 1) / as_world
+                    ops.occupancy_hog(blocks, lds, max(1, int(remote / (gbs * 1e3))), self._side)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             self._ready[slot] = ev

@@ -16,6 +16,7 @@ There is NO CPU path: all arithmetic goes through libvdx_hip.so (ops.py raises o
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
@@ -675,6 +676,14 @@ class UNet3DConditionModel(nn.Module):
         # 170 ms step) — and the prefix is shared when, and only when, they are equal.
         if not cfg_dup and self.detect_cfg_duplicate and self.share_cfg_prefix and B == 2:
             cfg_dup = bool(torch.equal(sample[0], sample[1]))
+        elif cfg_dup and B == 2 and (self.detect_cfg_duplicate or os.environ.get("VDX_VERIFY_CFG_DUP") == "1"):
+            # The tag rests on torch's version counter; a write that does not bump it (`x.data`, another library's raw-pointer
+            # kernel, a vdx op handed the tensor as `out=`) leaves a STALE tag, and the prefix would then compute one item for
+            # a batch whose items differ — wrong output, no error.  Under VDX_VERIFY_CFG_DUP=1 (tests/conftest.py sets it)
+            # and in detect mode (which pays the sync anyway) the claim is checked: a stale tag raises.
+            if not torch.equal(sample[0], sample[1]):
+                raise ops.VdxError("UNet3DConditionModel.forward: the batch is tagged as a CFG duplicate (ops.cfg_input) but its two items "
+                                   "differ: it was written after cfg_input by something that does not bump torch's version counter")
         dup = bool(self.share_cfg_prefix and B == 2 and cfg_dup and c.down_block_types[0].startswith("CrossAttn"))
         self.last_forward_shared_prefix = dup
         B1 = 1 if dup else B

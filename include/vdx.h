@@ -335,6 +335,25 @@ int vdx_allgather_shard(vdx_comm* comm, const void* shard, void* full, size_t sh
 int vdx_halo_exchange(vdx_comm* comm, const void* send_buf, size_t send_bytes, int send_to, void* recv_buf,
                       size_t recv_bytes, int recv_from, vdx_stream_t side_stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Persistent grids and the CUs a collective holds.  The weights-stationary GEMMs and the fused sub-block kernels (K5, K7,
+ * K8) launch one workgroup per compute unit.  While a parameter gather (fsdp_chunked_coherent.py:63-88's FSDP all-gather;
+ * here RCCL on a side stream) runs beside the step, each of its channel kernels holds a CU; an exact-fit grid then runs
+ * its displaced workgroups as a second round.  `vdx_set_reserved_cus(r)` makes every persistent grid leave r CUs free
+ * (rounded so the grid stays a multiple of 8 = the XCD count); results do not depend on r, bit for bit.  Process-wide,
+ * not thread-safe against concurrent launches; the shard store sets it once when world > 1 (vdx/shard.py).            */
+int vdx_set_reserved_cus(int n);
+int vdx_reserved_cus(void);
+int vdx_persistent_grid_cus(void);
+
+/* Box probes — not on the denoising path; bench.py's `box` object and the one-GPU rehearsal of the distributed path.
+ *   vdx_probe_mfma_f16      : a fixed dense v_mfma_f32_32x32x16_f16 stream (2 waves / SIMD, per-lane operands) on every CU;
+ *                             *flops = its FLOP count; time it with events around the call -> the part's sustained MFMA rate
+ *   vdx_probe_occupancy_hog : `blocks` workgroups x 256 threads holding `lds_bytes` of LDS each for `micros` us, touching
+ *                             no memory: stands in for the CUs a collective's channel kernels hold                        */
+int vdx_probe_mfma_f16(float* out, size_t out_floats, int iters, double* flops, vdx_stream_t stream);
+int vdx_probe_occupancy_hog(int blocks, int lds_bytes, int micros, vdx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

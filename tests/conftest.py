@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# every test run CHECKS the CFG-duplicate tag it relies on (unet3d.forward): a stale tag fails a test instead of producing a
+# wrong latent
+os.environ.setdefault("VDX_VERIFY_CFG_DUP", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
