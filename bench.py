@@ -347,7 +347,7 @@ def main():
             os.environ["VDX_SHARD_FORCE_COLLECTIVE"] = "1"
         if args.backend == "nccl":
             from vdx.shard import configure_rccl_env
-            configure_rccl_env()          # cap RCCL's channels (= CUs held beside the step) before the communicator exists
+            configure_rccl_env()          # the process group's stream on a hardware queue of its own, before the communicator exists
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -540,7 +540,7 @@ def main():
             out["shard_copies_per_gather"] = (store.rehearse_copies or store.world) if store.transport == "peer" else None
             out["shard_gather_host_ms_per_step"] = round(1e3 * (h1 - h0) / args.steps, 3)
             out["persistent_grid_reserved_cus"] = ops.reserved_cus()
-            out["rccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+            out["shard_prefetch_depth"] = store.prefetch_depth
             if store.rehearse_hog is not None:
                 out["rehearse_hog"] = {"cus_held": store.rehearse_hog[0], "lds_bytes": store.rehearse_hog[1],
                                        "modelled_allgather_gbs": store.rehearse_hog[2], "as_world": store.rehearse_hog[3]}

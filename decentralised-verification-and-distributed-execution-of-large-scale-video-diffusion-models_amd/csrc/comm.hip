@@ -134,6 +134,13 @@ extern "C" int vdx_ipc_export(const void* dev_ptr, void* handle64, size_t* offse
     size_t size = 0;
     hipError_t e = hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)dev_ptr);
     if (e != hipSuccess) return vdx_fail("ipc_export: hipMemGetAddressRange: %s", hipGetErrorString(e));
+    // What a handle exports is the whole ALLOCATION around the pointer (with torch: the caching allocator's segment).
+    // Measured on this driver (ROCm 7.2, dmabuf IPC; tools/peer_check.py, profiles/r06_peer_transport.md): arenas inside
+    // segments of up to 2000 MB open in the peer process and read back bit for bit; inside a segment of 2048 MB (and of
+    // 2600 MB) the peer's hipIpcOpenMemHandle never returns.  The guard sits at half the smallest size seen to fail.  Never
+    // hand out a handle the peer cannot open: the caller falls back to RCCL.
+    VDX_CHECK(size < ((size_t)1 << 30), "ipc_export: the allocation around the pointer is %zu bytes; HIP IPC mappings of allocations of "
+              "2 GiB or more do not open on this driver (guard: 1 GiB) - keep exported arenas in allocations of their own", size);
     e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, base);
     if (e != hipSuccess) return vdx_fail("ipc_export: hipIpcGetMemHandle: %s", hipGetErrorString(e));
     *offset_bytes = (size_t)((const char*)dev_ptr - (const char*)base);

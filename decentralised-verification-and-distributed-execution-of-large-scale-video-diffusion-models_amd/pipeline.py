@@ -214,7 +214,7 @@ def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_strea
         return got, None
     if ref.is_cuda and comm is not None:
         cur = torch.cuda.current_stream(ref.device)
-        side = side_stream or torch.cuda.Stream(device=ref.device)
+        side = side_stream or torch.cuda.Stream(device=ref.device, priority=-1)   # own hardware queue: vdx/shard.py on `_side`
         ready = torch.cuda.Event()
         ready.record(cur)
         side.wait_event(ready)
@@ -245,7 +245,7 @@ def exchange_halos(mine: List[torch.Tensor], hp: HaloPlan, rank: int, side_strea
         return got, None
     if ref.is_cuda:
         cur = torch.cuda.current_stream(ref.device)
-        side = side_stream or torch.cuda.Stream(device=ref.device)
+        side = side_stream or torch.cuda.Stream(device=ref.device, priority=-1)   # own hardware queue: vdx/shard.py on `_side`
         ready = torch.cuda.Event()
         ready.record(cur)                                   # pieces / buffers exist once `cur` gets here
         with torch.cuda.stream(side):

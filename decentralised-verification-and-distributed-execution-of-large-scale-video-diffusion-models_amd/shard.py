@@ -3,9 +3,9 @@ reference's `FSDP(pipe.unet, FULL_SHARD, ...)` wrap (`fsdp_chunked_coherent.py:6
 
 Every *unit* (one resnet, one temporal-conv stack, one spatial or temporal transformer, one
 resampler) owns a flat fp16 buffer; each GPU keeps 1/world of it.  During a forward the units are
-used strictly in order (`UNet3DConditionModel.unit_schedule`), so while unit k computes, unit k+1
-is gathered on a side HIP stream into the other of two gather buffers; a buffer is only overwritten
-after the compute stream has passed the unit that used it.  Inference only: no reduce-scatter.
+used strictly in order (`UNet3DConditionModel.unit_schedule`), so while unit k computes, units k+1
+and k+2 are gathered on a side HIP stream (prefetch depth 2, three gather buffers; round 6); a buffer is
+only overwritten after the compute stream has passed the unit that used it.  Inference only: no reduce-scatter.
 Sharding changes memory, never results.
 
 Transports of the gather (`transport=`, env VDX_SHARD_TRANSPORT):
@@ -15,12 +15,17 @@ Transports of the gather (`transport=`, env VDX_SHARD_TRANSPORT):
                 `world` device-to-device copies on the side stream (`vdx_peer_gather`): copy engines over xGMI, no compute
                 unit taken from the GEMMs that run meanwhile, no collective — parameters are read-only after load, so a
                 rank pulls what it needs when it needs it.  It was the default through round 4.  Round 5
-                ran it for the first time between two processes at FULL size (1.3 GB arenas, both ranks on the one GPU
-                of a box): the mapping opened but its self-check against the collective FAILED (the store fell back, as
-                designed), and a stand-alone probe of `hipIpcOpenMemHandle` on an arena of that size did not return
-                (profiles/r05_peer_transport.md).  Both ranks sat on one device there, which a node never has, but no node
-                was available to show the cross-device case works either — so the only multi-GPU run this build may
-                get goes through RCCL, and the peer transport stays available for whoever can measure it;
+                ran it for the first time between two processes at FULL size (ONE 1.3 GB arena per rank, both ranks on the
+                one GPU of a box): a failed self-check and a `hipIpcOpenMemHandle` that never returned.  Round 6 found
+                the cause with a staged probe under host-side deadlines (tools/peer_check.py, profiles/r06_peer_transport.md):
+                a handle exports the whole allocation around the pointer — here the caching allocator's segment — and a
+                mapping of an allocation of 2 GiB or more does not open on this driver (segments up to 2000 MB: open, read
+                back bit for bit, serialised or concurrent opens alike; 2048 MB and 2600 MB: never return).  Round 5's arena
+                had been carved out of a cached 2.6 GB block.  Nothing to do with concurrent opens or with the gloo gather
+                the self-check compares against.  The arenas are now allocations of their own of at most 256 MB
+                (`ARENA_BYTES`), `vdx_ipc_export` refuses an allocation of 1 GiB or more (the store then falls back to the
+                collective on every rank), and the full-size two-process run passes its self-check.  The cross-DEVICE
+                case still has never run (no multi-GPU node in any round), so RCCL stays the default;
   comm=         the C-ABI RCCL entry point `vdx_allgather_shard` (vdx/comm.py).
 
 The store is a read-only mapping (name -> tensor view) and is what `UNet3DConditionModel.W`
@@ -39,33 +44,36 @@ import torch.distributed as dist
 
 ALIGN = 64          # elements: keeps every view 128-byte aligned
 
-# RCCL's all-gather runs as `nchannels` workgroups, each holding a compute unit for the duration of the collective.  The
+# RCCL's all-gather runs as `nchannels` workgroups, each holding a compute unit for the duration of the collective, and the
 # weights-stationary GEMMs and K5 / K7 / K8 launch ONE workgroup per CU with up to 160 KB of LDS: beside a gather an exact-fit
-# grid leaves its displaced workgroups to a second round (up to 2x on those launches).  So for world > 1 the store (a) caps
-# RCCL at RCCL_CHANNELS channels (`configure_rccl_env`, before the communicator exists) and (b) makes every persistent grid
-# leave as many CUs free (`vdx_set_reserved_cus`; results do not depend on it).  The number comes from the one-GPU
-# occupancy-hog rehearsal, profiles/r06_rccl_contention.md; VDX_RESERVED_CUS / NCCL_MAX_NCHANNELS override.
-RCCL_CHANNELS = 16
+# grid leaves its displaced workgroups to a second round.  Round 6 PRICED that on one GPU (tools/rccl_contention.py,
+# profiles/r06_rccl_contention.md: an occupancy hog of R workgroups behind every gather for the time a ring all-gather of
+# the group's remote bytes takes): holding 1, 8, 16 or 32 CUs costs the SAME (+7 % of a 16-frame window at 100 GB/s: what the
+# gathers' DURATION exposes, not what they hold — the bytes sit at the 1280-channel levels, the persistent grids at levels
+# 0-1, and a grid that finds 16 CUs taken loses a third, not half), and a reserve of R CUs costs more (+1 %) than it saves.
+# Halving the gather RATE (4 channels at 50 GB/s) costs +18 %.  Hence: no channel cap (RCCL picks what moves bytes fastest),
+# no reserve by default (`vdx_set_reserved_cus` stays available: VDX_RESERVED_CUS), and the two things that DID matter:
+# the side stream on a hardware queue of its own (`_side` below: -18 ms) and prefetch depth 2 (`prefetch_depth`).
 
 
 def configure_rccl_env(env=None):
-    """Cap RCCL's channel count (= the CUs its kernels hold) unless the caller already chose: call BEFORE
-    `init_process_group` / the first collective (bench.py does; the launcher's environment is inherited by the ranks)."""
+    """Environment of a multi-GPU run, to be in place BEFORE `init_process_group` / the first collective (bench.py and its
+    launcher call this).  torch.distributed runs collectives on the process group's OWN stream: take it from the
+    high-priority pool, whose hardware queues the default (compute) stream never shares (ShardedStore.__init__ on `_side`)."""
     env = os.environ if env is None else env
-    env.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_CHANNELS))
-    env.setdefault("NCCL_MIN_NCHANNELS", str(min(RCCL_CHANNELS, 4)))
+    env.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
     return env
 
 
 def reserved_cus_for(world: int, transport: str) -> int:
-    """CUs the persistent grids leave to the collective's channel kernels: none for a world of one or for copy-engine
-    pulls (peer transport), else VDX_RESERVED_CUS or the RCCL channel cap in force."""
+    """CUs the persistent grids leave to a collective's channel kernels: VDX_RESERVED_CUS for a world > 1 on the collective
+    transport, else 0 (default 0: measured not to pay, see above)."""
     if world <= 1 or transport != "collective":
         return 0
-    v = os.environ.get("VDX_RESERVED_CUS")
-    if v is not None:
-        return int(v)
-    return int(os.environ.get("NCCL_MAX_NCHANNELS", RCCL_CHANNELS))
+    return int(os.environ.get("VDX_RESERVED_CUS", "0"))
+
+
+ARENA_BYTES = 256 << 20      # largest shard arena (= largest allocation ever exported through HIP IPC); see ShardedStore.__init__
 
 
 def _FORCE_COLLECTIVE():
@@ -107,7 +115,7 @@ def _ipc_release(lib, pid, handle):
 class ShardedStore:
     def __init__(self, tensors: Dict[str, torch.Tensor], unit_of: Callable[[str], Optional[str]],
                  schedule: List[str], rank: int, world: int, group=None, comm=None, transport: Optional[str] = None,
-                 merge_bytes: int = 64 << 20):
+                 merge_bytes: int = 64 << 20, prefetch_depth: int = 2):
         """`unit_of(name)` -> unit id, or None for tensors kept replicated (small stem tensors).
         `comm`: a `vdx.comm.Comm` — the gathers then go through the C-ABI (`vdx_allgather_shard`, RCCL) instead of
         `torch.distributed`.  `transport`: "collective" | "peer" (module docstring); default from VDX_SHARD_TRANSPORT,
@@ -137,33 +145,58 @@ class ShardedStore:
             self._unit_of[name] = u
             sizes[u] += _round_up(t.numel(), ALIGN)
         self._padded = {u: _round_up(max(n, 1), ALIGN * world) for u, n in sizes.items()}
-        # local shards: ONE arena (the units' 1/world slices back to back, the same layout on every rank), so that one
-        # IPC export per rank makes all of them reachable
-        self._arena_off: Dict[str, int] = {}
-        off = 0
+        # local shards: a few ARENAS (the units' 1/world slices back to back, the same layout on every rank), so that a
+        # handful of IPC exports per rank make all of them reachable.  An arena is at most ARENA_BYTES and an allocation of
+        # its own: a HIP IPC handle exports the whole allocation AROUND a pointer (the caching allocator's segment), and a
+        # mapping of an allocation of 2 GiB or more does not open on this driver (`hipIpcOpenMemHandle` never returns;
+        # measured round 6, profiles/r06_peer_transport.md: arenas in segments of up to 2000 MB open and read back, in
+        # segments of 2048 / 2600 MB they hang — round 5's single 1.3 GB arena had been carved out of a cached 2.6 GB
+        # block).  `vdx_ipc_export` refuses allocations of 1 GiB or more.  A unit never straddles two arenas.
+        es = any_t.element_size()
+        self._arena_off: Dict[str, tuple] = {}       # unit -> (arena index, element offset inside it)
+        sizes_a: List[int] = [0]
         for u in self.schedule:
-            self._arena_off[u] = off
-            off += self._padded[u] // world
-        self._arena = torch.zeros(max(off, 1), dtype=self.dtype, device=self.device)
+            n = self._padded[u] // world
+            if sizes_a[-1] and (sizes_a[-1] + n) * es > ARENA_BYTES:
+                sizes_a.append(0)
+            self._arena_off[u] = (len(sizes_a) - 1, sizes_a[-1])
+            sizes_a[-1] += n
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()     # an arena must be its OWN allocation (what gets exported is the allocation around it)
+        self._arenas = [torch.zeros(max(n, 1), dtype=self.dtype, device=self.device) for n in sizes_a]
         self.shards: Dict[str, torch.Tensor] = {}
         for u in self.schedule:
             flat = torch.zeros(self._padded[u], dtype=self.dtype, device=self.device)
             for name, o, shape in self._layout[u]:
                 flat[o:o + tensors[name].numel()] = tensors[name].reshape(-1)
             n = self._padded[u] // world
-            self.shards[u] = self._arena[self._arena_off[u]:self._arena_off[u] + n]
+            ai, ao = self._arena_off[u]
+            self.shards[u] = self._arenas[ai][ao:ao + n]
             self.shards[u].copy_(flat[rank * n:(rank + 1) * n])
             del flat
         cap = max(self._padded.values())
-        self._bufs = [torch.empty(cap, dtype=self.dtype, device=self.device) for _ in range(2)]
-        self._resident = [None, None]          # unit held by each buffer
-        self._ready = [None, None]             # event: gather into buffer finished
-        self._released = [None, None]          # event: compute stream is past the unit in that buffer
+        # prefetch depth d: while group k computes, groups k+1 .. k+d are gathered (or already there); d + 1 gather buffers.
+        # Depth 1 hides a gather only behind the ONE group before it, and at the deep levels (1280 channels: 60-95 MB of
+        # weights per group, 0.4-0.6 ms of compute at 16 frames) a gather outlasts that group: sum_k max(c_k, g_(k+1)).
+        # Depth 2 lets the gathers of the deep levels run on while the 1.5-ms groups around them compute
+        # (profiles/r06_rccl_contention.md); one more buffer of the largest group (95 MB).
+        self.prefetch_depth = max(1, int(prefetch_depth))
+        nb = self.prefetch_depth + 1
+        self._bufs = [torch.empty(cap, dtype=self.dtype, device=self.device) for _ in range(nb)]
+        self._resident = [None] * nb           # unit held by each buffer
+        self._ready = [None] * nb              # event: gather into buffer finished
+        self._released = [None] * nb           # event: compute stream is past the unit in that buffer
         self._view_cache: Dict = {}            # (slot, unit) -> {name: view}: built once, not per switch
         self._views: Dict[str, torch.Tensor] = {}
         self._current: Optional[str] = None
         self._cuda = self.device.type == "cuda"
-        self._side = torch.cuda.Stream(device=self.device) if self._cuda else None
+        # HIGH priority, and not for the priority's sake: HIP maps streams onto a few hardware queues (4 by default), two
+        # streams on one queue run in submission order, and every 4th normal-priority stream torch hands out — with a NCCL
+        # process group alive, the very FIRST — shares the queue of the default (compute) stream: the "side" stream then
+        # takes turns with the step instead of running beside it (measured round 6, tools/overlap_streams.py,
+        # profiles/r06_rccl_contention.md: a gather of modelled duration g made the step g longer whatever it held).
+        # High-priority streams live on queues of their own.
+        self._side = torch.cuda.Stream(device=self.device, priority=-1) if self._cuda else None
         self.gathers = 0
         self.transport = "collective"
         self.peer_self_check = "not run"       # "passed" | "failed" once a world > 1 store has compared peer vs collective
@@ -176,6 +209,7 @@ class ShardedStore:
             raise ValueError(f"unknown shard transport {want!r}")
         if want == "peer" and self._cuda and comm is None and (world > 1 or _FORCE_COLLECTIVE() or transport == "peer"):
             self._setup_peer()
+        self.trace = None                      # list to collect (group, event at entry on the compute stream): tools/rccl_contention.py
         self.rehearse_hog = None               # (blocks, lds bytes, modelled GB/s, as_world): one-GPU rehearsal of the CUs RCCL holds
         self.reserved_cus = 0
         if self._cuda:
@@ -189,27 +223,35 @@ class ShardedStore:
         all_gather_object).  Falls back to the collective transport, on every rank alike, if any rank fails."""
         from . import _lib
         lib = _lib.load()
-        torch.cuda.synchronize(self.device)          # the arena is complete before anybody may read it
-        handle, off = C.create_string_buffer(64), C.c_size_t(0)
-        rc = lib.vdx_ipc_export(self._arena.data_ptr(), handle, C.byref(off))
-        mine = (self.rank, os.getpid(), handle.raw if rc == 0 else None, off.value)
+        torch.cuda.synchronize(self.device)          # the arenas are complete before anybody may read them
+        exports = []                                 # per arena: (handle bytes | None, byte offset inside its allocation)
+        for a in self._arenas:
+            handle, off = C.create_string_buffer(64), C.c_size_t(0)
+            rc = lib.vdx_ipc_export(a.data_ptr(), handle, C.byref(off))      # refuses allocations of 1 GiB or more
+            exports.append((handle.raw if rc == 0 else None, off.value))
+        mine = (self.rank, os.getpid(), exports)
         if self.world > 1:
             infos = [None] * self.world
             dist.all_gather_object(infos, mine, group=self.group)
         else:
             infos = [mine]
-        ptrs, opened, ok = [None] * self.world, [], all(i[2] is not None for i in infos)
+        ptrs, opened = [None] * self.world, []       # ptrs[rank][arena] = address of that rank's arena in THIS process
+        ok = all(h is not None for i in infos for h, _ in i[2])
         if ok:
-            for r, pid, h, o in infos:
+            for r, pid, exps in infos:
                 if r == self.rank:
-                    ptrs[r] = self._arena.data_ptr()
+                    ptrs[r] = [a.data_ptr() for a in self._arenas]
                     continue
-                p = _ipc_acquire(lib, pid, h, o)
-                if p is None:
-                    ok = False
+                ptrs[r] = []
+                for h, o in exps:
+                    p = _ipc_acquire(lib, pid, h, o)
+                    if p is None:
+                        ok = False
+                        break
+                    ptrs[r].append(p)
+                    opened.append((pid, h))
+                if not ok:
                     break
-                ptrs[r] = p
-                opened.append((pid, h))
         if self.world > 1:       # everybody or nobody
             flags = [None] * self.world
             dist.all_gather_object(flags, ok, group=self.group)
@@ -236,10 +278,21 @@ class ShardedStore:
             else:
                 dist.all_gather(list(b.chunk(self.world)), self.shards[unit], group=self.group)
             torch.cuda.synchronize(self.device)
+            # BITWISE: the packed blobs of the fused kernels carry fp32 biases inside fp16-typed tensors, and some of those
+            # bit patterns read as fp16 NaNs — a float comparison calls identical bytes different (this, not the mapping,
+            # failed round 5's self-check: 96 + 326 such elements in the first unit, on the rank's OWN slice too)
+            ai_, bi_ = a.view(torch.int16), b.view(torch.int16)
+            same = bool(torch.equal(ai_, bi_))
+            detail = ""
+            if not same:       # which rank's slice differs, and how much of it: the first thing anybody debugging this needs
+                per = n // self.world
+                bad = [(r, int((ai_[r * per:(r + 1) * per] != bi_[r * per:(r + 1) * per]).sum())) for r in range(self.world)]
+                detail = (f" [rank {self.rank}: unit {unit!r}, {per} elements per slice, differing elements per owner rank "
+                          f"{bad}; arena {self._arena_off[unit]}, {len(self._arenas)} arenas]")
             flags = [None] * self.world
-            dist.all_gather_object(flags, bool(torch.equal(a, b)), group=self.group)
+            dist.all_gather_object(flags, same, group=self.group)
             if not all(flags):
-                warnings.warn("ShardedStore: the peer-mapped gather does not reproduce the collective one; using the collective all-gather")
+                warnings.warn("ShardedStore: the peer-mapped gather does not reproduce the collective one; using the collective all-gather" + detail)
                 self._close_peer()
             self.peer_self_check = "passed" if self.transport == "peer" else "failed"
 
@@ -274,14 +327,15 @@ class ShardedStore:
         es = out.element_size()
         n = self._padded[unit] // self.world
         k = self.rehearse_copies
+        ai, ao = self._arena_off[unit]
         if k > 1 and self.world == 1 and (n * es) % (16 * k) == 0:
             # one-GPU rehearsal of a bigger world (bench.py --as-world): the same bytes as `k` copies, so that the host
             # issues what it would issue on a node (one ctypes call, k hipMemcpyAsync per unit)
-            base = self._peer_ptrs[0] + self._arena_off[unit] * es
+            base = self._peer_ptrs[0][ai] + ao * es
             srcs = (C.c_void_p * k)(*[base + i * (n * es // k) for i in range(k)])
             rc = _lib.load().vdx_peer_gather(out.data_ptr(), srcs, k, n * es // k, self._side.cuda_stream)
         else:
-            srcs = (C.c_void_p * self.world)(*[p + self._arena_off[unit] * es for p in self._peer_ptrs])
+            srcs = (C.c_void_p * self.world)(*[p[ai] + ao * es for p in self._peer_ptrs])
             rc = _lib.load().vdx_peer_gather(out.data_ptr(), srcs, self.world, n * es, self._side.cuda_stream)
         _lib.check(rc, "vdx_peer_gather")
 
@@ -330,6 +384,7 @@ class ShardedStore:
             with torch.cuda.stream(self._side):
                 if self._released[slot] is not None:
                     self._side.wait_event(self._released[slot])     # old contents no longer needed
+                    self._released[slot] = None                     # (the event belonged to the old contents)
                 run()
                 if self.rehearse_hog is not None:
                     # one-GPU rehearsal: hold `blocks` CUs for as long as a ring all-gather of this group's REMOTE bytes
@@ -347,18 +402,37 @@ class ShardedStore:
         self._resident[slot] = unit
         self.gathers += 1
 
+    def _pick_slot(self, pos: int, protect) -> int:
+        """Buffer to overwrite: never one in `protect`; an empty one if any; else the one whose group is needed LATEST
+        counting forward from schedule position `pos` (the group just left is L - 1 steps away: the first to go)."""
+        best, best_d = None, -1
+        L = len(self.schedule)
+        for s_, u in enumerate(self._resident):
+            if s_ in protect:
+                continue
+            if u is None:
+                return s_
+            d = (self._pos[u] - pos) % L
+            if d > best_d:
+                best, best_d = s_, d
+        return best
+
     def _switch_to(self, unit: str):
+        if self.trace is not None and self._cuda:      # diagnostic: when does the compute stream ENTER each gather group
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.trace.append((unit, ev))
         # release the buffer of the unit we are leaving
-        if self._current is not None and self._cuda:
+        if self._current is not None and self._cuda and self._current in self._resident:
             old = self._resident.index(self._current)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self._released[old] = ev
+        pos = self._pos[unit]
         if unit in self._resident:
             slot = self._resident.index(unit)
         else:                                                   # not prefetched: gather on demand
-            cur = self._resident.index(self._current) if self._current in self._resident else 1
-            slot = cur ^ 1                                      # keep the just-released buffer for the prefetch
+            slot = self._pick_slot(pos, ())
             self._gather_into(slot, unit)
         if self._cuda and self._ready[slot] is not None:
             torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
@@ -369,10 +443,22 @@ class ShardedStore:
             self._view_cache[(slot, unit)] = views
         self._views = views
         self._current = unit
-        # prefetch the next unit of the schedule into the other buffer
-        nxt = self.schedule[(self._pos[unit] + 1) % len(self.schedule)]
-        if nxt != unit and nxt not in self._resident:
-            self._gather_into(slot ^ 1, nxt)
+        # prefetch the next `prefetch_depth` units of the schedule into the buffers that hold nothing still needed
+        L = len(self.schedule)
+        ahead = []
+        for d in range(1, self.prefetch_depth + 1):
+            nxt = self.schedule[(pos + d) % L]
+            if nxt == unit or nxt in ahead:
+                break
+            ahead.append(nxt)
+        for nxt in ahead:
+            if nxt in self._resident:
+                continue
+            protect = {slot} | {self._resident.index(u) for u in ahead if u in self._resident}
+            tgt = self._pick_slot(pos, protect)
+            if tgt is None:
+                break
+            self._gather_into(tgt, nxt)
 
 
 def _merge_units(tensors, unit_of, schedule, merge_bytes):

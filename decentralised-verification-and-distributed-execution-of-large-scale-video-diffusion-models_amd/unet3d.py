@@ -301,14 +301,16 @@ class UNet3DConditionModel(nn.Module):
             return ".".join(parts[:3])
         return None                              # conv_in/out, time embedding, conv_norm_out
 
-    def shard_(self, rank: int, world: int, group=None, comm=None, transport=None, merge_bytes: int = 64 << 20):
+    def shard_(self, rank: int, world: int, group=None, comm=None, transport=None, merge_bytes: int = 64 << 20,
+               prefetch_depth: int = 2):
         """Keep 1/world of every unit on this GPU; gather per unit with prefetch (vdx/shard.py).  `comm`: gather through
         the C-ABI RCCL entry point instead of torch.distributed (vdx/comm.py); `transport`: "collective" (RCCL all-gather on the
         side stream: the default) or "peer" (mapped shard arenas, copy-engine pulls: opt-in, vdx/shard.py)."""
         from .shard import ShardedStore
         if not isinstance(self.W, dict):
             raise VdxError("weights are already sharded")
-        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group, comm, transport, merge_bytes)
+        self.W = ShardedStore(self.W, self.unit_of, self.unit_schedule(), rank, world, group, comm, transport, merge_bytes,
+                              prefetch_depth)
         self.ff_block_bytes = 128 << 20
         if self._device.type == "cuda":
             torch.cuda.empty_cache()

@@ -15,18 +15,20 @@ GLOO_SCRIPT = r"""
 import sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
 import vdx
+import vdx.shard
 from vdx.shard import ShardedStore
 from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
 from vdx.weights import synthetic_state_dict
+vdx.shard.ARENA_BYTES = {arena_bytes}
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 cfg = UNet3DConfig(block_out_channels=(64, 128, 128, 128), cross_attention_dim=128, transformer_in_heads=2)
 m = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, seed=5), device="cpu")
 full = dict(m.W)
 total = sum(t.numel() for t in full.values()) * 2
-m.shard_(rank, world)
+m.shard_(rank, world, prefetch_depth={depth})
 st = m.W
-assert isinstance(st, ShardedStore) and set(st.keys()) == set(full)
+assert isinstance(st, ShardedStore) and set(st.keys()) == set(full) and len(st._bufs) == {depth} + 1
 # schedule order (what forward does), twice (second pass uses the wrap-around prefetch)
 by_unit = {{}}
 for k in full:
@@ -46,14 +48,26 @@ for u in list(reversed(m.unit_schedule()))[:7]:
 shard_bytes = sum(s.numel() for s in st.shards.values()) * 2
 sharded_total = sum(full[k].numel() for u in m.unit_schedule() for k in by_unit[u]) * 2
 assert shard_bytes <= sharded_total / world * 1.02 + 4096 * n_sched, (shard_bytes, sharded_total)
+# the arenas: none above the cap (unless one unit alone is), every unit inside exactly one, shards are views of them
+es = 2
+assert len(st._arenas) >= {min_arenas}, len(st._arenas)
+for a in st._arenas:
+    assert a.numel() * es <= max(vdx.shard.ARENA_BYTES, max(st._padded.values()) // world * es)
+for u, (ai, ao) in st._arena_off.items():
+    n = st._padded[u] // world
+    assert ao + n <= st._arenas[ai].numel() and st.shards[u].data_ptr() == st._arenas[ai].data_ptr() + ao * es
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok", st.gathers)
 """
 
 
-def test_shard_store_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("arena_bytes,min_arenas,depth", [(256 << 20, 1, 2), (1 << 20, 4, 1), (1 << 20, 4, 3)],
+                         ids=["one-arena-depth2", "many-arenas-depth1", "many-arenas-depth3"])
+def test_shard_store_two_ranks_gloo(tmp_path, arena_bytes, min_arenas, depth):
+    """`many-arenas`: the cap lowered to 1 MB so that the tiny model's shards spread over several arenas — the layout the XL
+    model has at its 256 MB cap (an exported allocation must stay under 1 GiB: vdx/shard.py)."""
     script = tmp_path / "shard.py"
-    script.write_text(GLOO_SCRIPT.format(root=ROOT))
+    script.write_text(GLOO_SCRIPT.format(root=ROOT, arena_bytes=arena_bytes, min_arenas=min_arenas, depth=depth))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
                        capture_output=True, text=True, timeout=600)

@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """Per-launch time guard for the dominant kernels (an 11 % regression of the 3x3-conv kernel went unnoticed for
 half a round).  Compares the rocprofv3 --kernel-trace --stats averages of a fresh run with a committed profile and FAILS
-(exit 1) when a guarded kernel's average launch got more than --tol (4 %) slower than the BOX (boxes of the pool differ by
-several per cent as a whole: the median ratio of the guarded kernels is taken as the box factor), or 2 x tol outright.
+(exit 1) when a guarded kernel's average launch got more than --tol (4 %) slower than the BOX, or 2 x tol outright.  Boxes
+of the pool differ by several per cent as a whole.  The box factor is the ratio of the two runs' MFMA PROBES when both bench
+lines carry one (`box.mfma_probe_tflops`, round 6: a fixed instruction stream measured in the bench process — independent
+of the kernels being judged); without probes, the median ratio of the guarded kernels (rounds 4-5).
 
-    python tools/perf_guard.py gpurun_out/rNN/kernel_stats.csv profiles/r03_kernel_stats.csv [--tol 0.04]"""
+    python tools/perf_guard.py gpurun_out/rNN/kernel_stats.csv profiles/r03_kernel_stats.csv [--tol 0.04]
+                               [--bench-new gpurun_out/rNN/bench.json --bench-ref profiles/r0M_bench.json]"""
 import argparse
 import csv
+import json
 import sys
 
 GUARDED = (
@@ -30,11 +34,24 @@ def load(path):
     return rows
 
 
+def probe_of(path):
+    """box.mfma_probe_tflops of a bench line file (the last JSON line in it), or None."""
+    if not path:
+        return None
+    try:
+        lines = [ln for ln in open(path).read().splitlines() if ln.lstrip().startswith("{")]
+        return float(json.loads(lines[-1])["box"]["mfma_probe_tflops"])
+    except (OSError, ValueError, KeyError, IndexError, TypeError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("new")
     ap.add_argument("ref")
     ap.add_argument("--tol", type=float, default=0.04)
+    ap.add_argument("--bench-new", default=None, help="bench line (JSON file) of the new run: its box.mfma_probe_tflops")
+    ap.add_argument("--bench-ref", default=None, help="bench line of the reference run")
     a = ap.parse_args()
     new, ref = load(a.new), load(a.ref)
     rows = []
@@ -51,7 +68,13 @@ def main():
     # kernels with an unchanged shape mix; a kernel fails when it is > tol slower than the box, or > 2 tol slower outright
     ratios = sorted(tn / tr for _, tn, tr, _, _, ok in rows if ok)
     box = ratios[len(ratios) // 2] if ratios else 1.0
-    print(f"  box factor (median ratio of the guarded kernels): {box:.3f}")
+    probes = [probe_of(a.bench_new), probe_of(a.bench_ref)]
+    if all(probes):
+        print(f"  box factor from the MFMA probes (reference {probes[1]:.1f} / new {probes[0]:.1f} TFLOP/s): {probes[1] / probes[0]:.3f}"
+              f"   [median ratio of the guarded kernels: {box:.3f}]")
+        box = probes[1] / probes[0]
+    else:
+        print(f"  box factor (median ratio of the guarded kernels; no MFMA probe in {'either' if not any(probes) else 'one'} bench line): {box:.3f}")
     bad = 0
     for g, tn, tr, cn, cr, ok in rows:
         raw, rel = tn / tr - 1.0, tn / tr / box - 1.0
