@@ -49,6 +49,15 @@ class DiffuserConfig:
     device: str = "cuda"
     noise_device: Optional[str] = None     # None = like the reference: generate on `device`
     overlap_rule: str = "coherent"
+    # the rest of the reference's argparse (`:281-300`): the job's front end (`run_job` / `main` below)
+    model_id: str = "cerspense/zeroscope_v2_XL"
+    prompt: str = "a rocket in space, 4k"
+    fps: int = 8
+    out_csv: str = "results.csv"
+    # network emulation (`:195-199,257-258`): sleeps in front of the chunk exchange and the memory reduction
+    emu_bw_mbps: float = 0.0               # throttle: payload_bytes / (Mbps * 1e6 / 8) seconds before the gather (0 = off)
+    emu_rtt_ms: float = 0.0                # one-way latency: gauss(rtt, jitter) ms before the gather, rtt ms before the reduction
+    emu_jitter_ms: float = 0.0
 
     @property
     def use_fsdp(self):
@@ -61,6 +70,24 @@ class DiffuserConfig:
     @property
     def use_ctx(self):
         return self.mode == "hybrid_ctx"
+
+
+def emu_gather_delay_s(payload_bytes: int, cfg, rng=None) -> float:
+    """Seconds the reference sleeps in front of `all_gather_object` (:195-199): `payload_bytes / (emu_bw_mbps * 1e6 / 8)` when
+    a bandwidth is given, plus `max(0, gauss(emu_rtt_ms, emu_jitter_ms)) / 1000` when a latency is (the reference draws from
+    the `random` module's global generator; `rng` = a `random.Random` for a reproducible draw)."""
+    import random
+    d = 0.0
+    if cfg.emu_bw_mbps > 0:
+        d += payload_bytes / (cfg.emu_bw_mbps * 1e6 / 8)
+    if cfg.emu_rtt_ms > 0:
+        d += max(0.0, (rng or random).gauss(cfg.emu_rtt_ms, cfg.emu_jitter_ms) / 1000.0)
+    return d
+
+
+def emu_reduce_delay_s(cfg) -> float:
+    """Seconds the reference sleeps in front of the peak-memory `all_reduce` (:257-258)."""
+    return cfg.emu_rtt_ms / 1000.0 if cfg.emu_rtt_ms > 0 else 0.0
 
 
 def _world():
@@ -378,6 +405,11 @@ class DistributedVideoDiffuser:
         denoise_s = time.time() - t0
         info = {"chunk_size": cp.chunk, "overlap": cp.overlap, "ranges": list(cp.ranges), "world_size": self.world,
                 "num_frames": T, "denoise_s": denoise_s, "exchange": exchange}
+        payload_ref = sum(t.shape[2] * C * 2 for t in mine)                 # the reference's `payload_bytes` (:194)
+        delay = emu_gather_delay_s(payload_ref, cfg)                        # :195-199, outside the timed gather like there
+        if delay > 0:
+            time.sleep(delay)
+        info["emu_gather_delay_s"] = delay
         t0 = time.time()
         if exchange == "allgather":
             chunks = gather_chunks(mine, cp, self.rank, self.world)
@@ -402,3 +434,125 @@ class DistributedVideoDiffuser:
         info["payload_bytes_actual"] = sum(t.numel() * 2 for t in mine)
         info["owned"] = [(s, e) for s, e, _ in owned]
         return owned, info
+
+
+# ---------------------------------------------------------------------------------------------
+# the job's front end: the reference's `main()` (:279-340) on this build's own driver
+# ---------------------------------------------------------------------------------------------
+def build_arg_parser():
+    """The reference's argparse, flag for flag and default for default (`fsdp_chunked_coherent.py:281-300`) — the sweep script
+    `Distribution/full_experiments_ZeroscopeXL.sh` drives the job through these.  Two additions, both off by default:
+    `--exchange` (allgather | halo, the module docstring) and `--noise_device` (parity runs generate the seeded noise on the CPU)."""
+    import argparse
+    p = argparse.ArgumentParser(description="hybrid FSDP + frame-chunked video denoising on the HIP path")
+    p.add_argument("--model_id", default="cerspense/zeroscope_v2_XL")
+    p.add_argument("--prompt", default="a rocket in space, 4k")
+    p.add_argument("--num_frames", type=int, default=32)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--guidance_scale", type=float, default=7.5)
+    p.add_argument("--chunk_size", type=int, default=0)
+    p.add_argument("--overlap", type=int, default=4)
+    p.add_argument("--fps", type=int, default=8)
+    p.add_argument("--height", type=int, default=576)
+    p.add_argument("--width", type=int, default=1024)
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--mode", choices=["fsdp", "chunk", "hybrid", "hybrid_ctx"], default="hybrid_ctx")
+    p.add_argument("--context_weight", type=float, default=0.35)
+    p.add_argument("--emu_bw_mbps", type=float, default=0, help="throttle bandwidth in Mbps (0 = no throttle)")
+    p.add_argument("--emu_rtt_ms", type=float, default=0, help="one-way latency in ms (0 = no extra delay)")
+    p.add_argument("--emu_jitter_ms", type=float, default=0, help="jitter stddev in ms (0 = no jitter)")
+    p.add_argument("--out_csv", default="results.csv")
+    p.add_argument("--exchange", choices=["allgather", "halo"], default="allgather")
+    p.add_argument("--noise_device", default=None)
+    p.add_argument("--out_video", default="out.mp4")
+    return p
+
+
+def config_from_args(a) -> DiffuserConfig:
+    return DiffuserConfig(num_frames=a.num_frames, steps=a.steps, guidance_scale=a.guidance_scale, chunk_size=a.chunk_size,
+                          overlap=a.overlap, height=a.height, width=a.width, mode=a.mode, context_weight=a.context_weight,
+                          device=a.device, noise_device=a.noise_device, model_id=a.model_id, prompt=a.prompt, fps=a.fps,
+                          out_csv=a.out_csv, emu_bw_mbps=a.emu_bw_mbps, emu_rtt_ms=a.emu_rtt_ms, emu_jitter_ms=a.emu_jitter_ms)
+
+
+def run_job(cfg: DiffuserConfig, exchange: str = "allgather", out_video: Optional[str] = "out.mp4", pipe=None) -> dict:
+    """The reference's `DistributedVideoDiffuser(cfg)()` (:47-276) end to end -> its result dict (:263-275): pipeline
+    components (`model_id` = a local checkpoint directory in diffusers layout, else seeded synthetic weights: nothing can be
+    downloaded here), text embeddings (:96-103), chunked denoising + exchange + blend, per-frame VAE decode (:219-225),
+    boundary metrics (:227-247) and the mp4 (:250-253) on rank 0, peak memory reduced over the ranks (:255-261)."""
+    import os
+
+    from . import metrics
+    from .compat.diffusers_shim import DiffusionPipeline
+    from .compat import pynvml_shim
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1 and not dist.is_initialized():
+        from .shard import configure_rccl_env
+        configure_rccl_env()
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
+    dev = torch.device(cfg.device if cfg.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+    if pipe is None:
+        pipe = DiffusionPipeline.from_pretrained(cfg.model_id, torch_dtype=torch.float16, low_cpu_mem_usage=True,
+                                                 use_safetensors=False, device_map=None)
+    unet = pipe.unet
+    unet.detect_cfg_duplicate = False           # this driver builds its CFG batch with ops.cfg_input: tagged, no compare needed
+    for m in (unet, pipe.text_encoder, pipe.vae):
+        m.to(dev)
+    tok = pipe.tokenizer
+    ids = tok([cfg.prompt, ""], padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
+    with torch.no_grad():
+        emb = pipe.text_encoder(ids.to(dev))[0]
+    cond, uncond = emb[:1].contiguous(), emb[1:].contiguous()
+    d = DistributedVideoDiffuser(cfg, unet, pipe.scheduler, uncond, cond)
+    out, info = d(exchange=exchange)
+    ranges = info["ranges"]
+    if exchange == "allgather":
+        frames = d.decode_frames(out, pipe.vae)
+    else:                                       # every rank decodes the frames it owns; rank 0 collects them for the metrics / mp4
+        mine = [(s, d.decode_frames(lat, pipe.vae)) for s, _e, lat in out]
+        allf = [None] * d.world
+        if d.world > 1:
+            dist.all_gather_object(allf, mine)
+        else:
+            allf = [mine]
+        frames = [f for _s, fr in sorted((x for lst in allf for x in lst), key=lambda x: x[0]) for f in fr]
+    temp_instab = flow_err = None
+    if d.rank == 0 and len(frames) > 1 and not cfg.no_chunking:
+        temp_instab = metrics.boundary_l1(frames, ranges)
+        flow_err = metrics.flow_warp_error(frames, ranges)
+    if d.rank == 0 and out_video:
+        metrics.write_video(frames, out_video, cfg.fps)
+    delay = emu_reduce_delay_s(cfg)             # :257-258
+    if delay > 0:
+        time.sleep(delay)
+    peak_mb, reduce_s = metrics.peak_vram_mb(dev)
+    pynvml_shim.nvmlInit()
+    end_mb = pynvml_shim.nvmlDeviceGetMemoryInfo(pynvml_shim.nvmlDeviceGetHandleByIndex(dev.index or 0)).used // 1024 ** 2
+    return {"world_size": d.world, "chunk_size": info["chunk_size"], "overlap": info["overlap"], "num_frames": cfg.num_frames,
+            "peak_vram_mb": peak_mb, "end_vram_mb": int(end_mb), "network_bytes": int(info["payload_bytes"]),
+            "net_gather_s": info["net_gather_s"], "net_reduce_s": reduce_s, "temp_instab": temp_instab, "flow_err": flow_err,
+            "denoise_s": info["denoise_s"], "exchange": exchange, "rank": d.rank, "synthetic_weights": pipe.synthetic_weights}
+
+
+def main(argv=None) -> int:
+    """`python -m vdx.pipeline [the reference's flags]` (one process, or under torchrun like the reference's script): runs the
+    job and appends the reference's CSV row (:313-333) to `--out_csv` on rank 0."""
+    from . import metrics
+    a = build_arg_parser().parse_args(argv)
+    cfg = config_from_args(a)
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+    t0 = time.time()
+    res = run_job(cfg, exchange=a.exchange, out_video=a.out_video)
+    if res["rank"] == 0:
+        row = metrics.result_row(res, mode=cfg.mode, num_frames=cfg.num_frames, elapsed_s=time.time() - t0)
+        metrics.append_csv(cfg.out_csv, row)
+        print(f"Metrics appended ->  {cfg.out_csv}")
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -9,8 +9,13 @@ owns on the hot path — `Distribution/strategies/fsdp_chunked_coherent.py`:
   ramp blend         :204-217
 
 Everything is written as straight-line torch-CPU code with the reference's
-dtypes (fp16 tensors, fp32 0-d scalars).  Parity status: planner/blend pinned
-by hand-executed known answers; denoise unpinned (oracle/__init__.py).
+dtypes (fp16 tensors, fp32 0-d scalars).  Parity status (round 5 on): PINNED TO THE
+EXECUTED REFERENCE — `tests/golden/make_ref_fixtures.py` ran the reference's four strategy
+files unmodified (worlds 1-8 over gloo) and `tests/test_ref_exec_host.py` requires `==` /
+`torch.equal` between this file and what they computed: 1 575 planner configurations, the
+shared noise and its slices, the broadcast context, every denoised chunk of eight
+"exact"-UNet jobs (3-50 steps), gather order, every blended frame, the CSV row.  What
+stays unpinned is the diffusers boundary those jobs stand in for (oracle/__init__.py).
 """
 from __future__ import annotations
 

@@ -55,3 +55,37 @@ def test_from_pretrained_directory_end_to_end(gpu, tmp_path):
     assert emb.shape == (2, 77, 128) and bool(torch.isfinite(emb.float()).all())
     img = pipe.vae.decode(torch.randn(1, 4, 8, 8, device=gpu, dtype=torch.float16) / pipe.vae.config.scaling_factor).sample
     assert img.shape == (1, 3, 64, 64) and bool(torch.isfinite(img.float()).all())
+
+
+def test_front_end_writes_the_reference_csv_row(gpu, tmp_path):
+    """`python -m vdx.pipeline` with the reference's flags (fsdp_chunked_coherent.py:281-300) on tiny synthetic weights: the job
+    runs end to end (text tower, chunked denoising, exchange, blend, VAE decode, boundary metrics, mp4, memory) and appends
+    the reference's CSV row; `--emu_*` sleep as the reference does (:195-199, 257-258); both exchanges give the same frames."""
+    import csv
+    import time
+    import vdx  # noqa: F401
+    from vdx import metrics
+    from vdx.pipeline import main
+    from vdx.planner import plan
+    out_csv, mp4 = str(tmp_path / "r.csv"), str(tmp_path / "o.mp4")
+    base = ["--model_id", "synthetic:tiny", "--num_frames", "10", "--steps", "2", "--height", "128", "--width", "256", "--chunk_size", "6",
+            "--overlap", "2", "--mode", "hybrid_ctx", "--out_csv", out_csv, "--out_video", mp4, "--noise_device", "cpu"]
+    t0 = time.time()
+    assert main(base) == 0
+    plain_s = time.time() - t0
+    t0 = time.time()
+    assert main(base + ["--emu_rtt_ms", "300", "--emu_bw_mbps", "0.001", "--exchange", "halo"]) == 0
+    emu_s = time.time() - t0
+    rows = list(csv.DictReader(open(out_csv)))
+    assert list(rows[0].keys()) == metrics.CSV_HEADER and len(rows) == 2
+    cp = plan(10, 1, 6, 2)
+    for r in rows:
+        assert r["mode"] == "hybrid_ctx" and int(r["world_size"]) == 1 and int(r["num_frames"]) == 10
+        assert (int(r["chunk_size"]), int(r["overlap"])) == (cp.chunk, cp.overlap)
+        assert int(r["network_bytes"]) == sum((e - s) * 4 * 2 for s, e in cp.ranges)          # :194
+        assert float(r["latency_s"]) > 0 and float(r["throughput_fps"]) > 0 and int(r["peak_vram_mb"]) > 0
+        assert r["temp_instab"] != "" and r["flow_err"] != ""                                 # two chunks: one boundary
+    assert rows[0]["temp_instab"] == rows[1]["temp_instab"]          # halo and allgather blend to the same frames
+    # 0.3 s (gauss(300, 0)) + 0.3 s before the reduction + payload / (0.001 Mbps) = 80 B / 125 B/s = 0.64 s
+    assert emu_s - plain_s > 1.0, (plain_s, emu_s)
+    assert os.path.getsize(mp4) > 1000

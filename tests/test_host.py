@@ -489,3 +489,51 @@ def test_k5_counted_waits_match_the_emitted_isa(tmp_path):
                    check=True, timeout=900)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k5_check_waits.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0 and " 0 mismatching" in r.stdout, r.stdout + r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the job's front end (vdx/pipeline.py: build_arg_parser / config_from_args / emu_*): the reference's argparse and its
+# network-emulation sleeps on the build's own driver
+# ---------------------------------------------------------------------------------------------------------------
+def test_front_end_has_the_reference_flags_and_defaults():
+    """`fsdp_chunked_coherent.py:281-300`, flag for flag: name, type and default — `full_experiments_ZeroscopeXL.sh:25-92`
+    drives the job through exactly these."""
+    import vdx  # noqa: F401
+    from vdx.pipeline import DiffuserConfig, build_arg_parser, config_from_args
+    ref = {"model_id": "cerspense/zeroscope_v2_XL", "prompt": "a rocket in space, 4k", "num_frames": 32, "steps": 50,
+           "guidance_scale": 7.5, "chunk_size": 0, "overlap": 4, "fps": 8, "height": 576, "width": 1024, "device": "cuda",
+           "mode": "hybrid_ctx", "context_weight": 0.35, "emu_bw_mbps": 0, "emu_rtt_ms": 0, "emu_jitter_ms": 0,
+           "out_csv": "results.csv"}
+    p = build_arg_parser()
+    a = p.parse_args([])
+    for k, v in ref.items():
+        assert getattr(a, k) == v and type(getattr(a, k)) is type(v), k
+    mode = [x for x in p._actions if x.dest == "mode"][0]
+    assert list(mode.choices) == ["fsdp", "chunk", "hybrid", "hybrid_ctx"]
+    for flag, typ in (("--num_frames", int), ("--steps", int), ("--guidance_scale", float), ("--emu_bw_mbps", float),
+                      ("--emu_rtt_ms", float), ("--emu_jitter_ms", float), ("--context_weight", float), ("--fps", int)):
+        assert [x for x in p._actions if flag in x.option_strings][0].type is typ, flag
+    cfg = config_from_args(p.parse_args("--mode hybrid --num_frames 48 --emu_bw_mbps 100 --emu_rtt_ms 20 --emu_jitter_ms 2".split()))
+    assert isinstance(cfg, DiffuserConfig) and (cfg.use_fsdp, cfg.no_chunking, cfg.use_ctx) == (True, False, False)    # :302-304
+    assert (cfg.num_frames, cfg.emu_bw_mbps, cfg.emu_rtt_ms, cfg.emu_jitter_ms) == (48, 100.0, 20.0, 2.0)
+    assert config_from_args(p.parse_args(["--mode", "fsdp"])).no_chunking and not config_from_args(p.parse_args(["--mode", "chunk"])).use_fsdp
+
+
+def test_network_emulation_sleeps_follow_the_reference():
+    """:195-199 — `sleep(payload_bytes / (emu_bw_mbps * 1e6 / 8))`, then `sleep(max(0, gauss(rtt, jitter)) / 1000)`; :257-258 —
+    `sleep(emu_rtt_ms / 1000)` before the reduction.  payload_bytes is the reference's formula (frames x channels x 2)."""
+    import random
+    import vdx  # noqa: F401
+    from vdx.pipeline import DiffuserConfig, emu_gather_delay_s, emu_reduce_delay_s
+    off = DiffuserConfig()
+    assert emu_gather_delay_s(10 ** 9, off) == 0.0 and emu_reduce_delay_s(off) == 0.0
+    payload = 16 * 4 * 2                                     # one 16-frame chunk: (e - s) * in_channels * 2  (:194)
+    bw = DiffuserConfig(emu_bw_mbps=1.0)
+    assert emu_gather_delay_s(payload, bw) == payload / (1.0 * 1e6 / 8) == 0.001024
+    rtt = DiffuserConfig(emu_rtt_ms=20.0, emu_jitter_ms=0.0)
+    assert abs(emu_gather_delay_s(payload, rtt) - 0.020) < 1e-12 and emu_reduce_delay_s(rtt) == 0.020
+    both = DiffuserConfig(emu_bw_mbps=8.0, emu_rtt_ms=10.0, emu_jitter_ms=3.0)
+    want = payload / 1e6 + max(0.0, random.Random(5).gauss(10.0, 3.0) / 1000.0)
+    assert abs(emu_gather_delay_s(payload, both, random.Random(5)) - want) < 1e-12
+    neg = DiffuserConfig(emu_rtt_ms=0.001, emu_jitter_ms=50.0)          # a negative draw sleeps 0, never a negative time
+    assert min(emu_gather_delay_s(0, neg, random.Random(s)) for s in range(50)) == 0.0
