@@ -57,7 +57,17 @@ struct Ws {
     static constexpr int MT = ROWS / 16;            // 16-row groups per chunk
     static constexpr int SUBT = ROWS * 128;         // one sub-tile: [ROWS rows][64 K-elements]
     static constexpr int STAGE = ROWS * K * 2;      // K/64 sub-tiles
-    static constexpr int NS = 3;                    // ring stages
+    // Ring stages: FOUR for K = 640 where they fit beside the GELU table / the weight sets' bias page (32 rows x 640: 4 x 40 KB
+    // = the CU's 160 KB exactly), else three (K = 320 with its 64-row chunks measured 2-4 % SLOWER on four: profiles/r06_ws_ring.md).  The kernel is bound by HBM LATENCY, not bandwidth: the blocks of a
+    // row group fetch the same chunk, so the chip has groups x (NS - 1) x 40 KB of reads in flight — 6.8 MB with three stages,
+    // which at ~2 us of loaded latency is the ~3 TB/s these launches measured (round 5 PMC: 2.2-3.0 TB/s, 24-40 % MFMA busy);
+    // a fourth stage puts half as much again in flight (round 6, profiles/r06_ws_ring.md).
+#ifdef VDX_WS_NS3
+    static constexpr int NS = 3;
+#else
+    static constexpr int NS = (K == 640 && 4 * STAGE + (GEGLU ? GELU_TAB_BYTES : 0) + (WSET ? NW * 64 * 32 : 0) <= 160 * 1024) ? 4 : 3;
+#endif
+    static constexpr int PF = NS - 1;               // chunks requested ahead of the one being computed
     static constexpr int PPW = STAGE / 1024 / NW;   // DMA instructions per wave and chunk
     static constexpr int RB = ROWS / 8;             // 8-row DMA blocks per sub-tile
     static_assert(PPW * NW * 1024 == STAGE, "chunk must split evenly over the waves");
@@ -94,18 +104,33 @@ struct Ws {
         }
     }
     // Chunk k has landed once at most the operations issued after its DMA are outstanding (vector-memory
-    // operations retire in order): the DMA of chunk k+1 and the stores of the two epilogues issued since
-    // (chunks k-2, k-1; with PIPE, whose epilogue runs one chunk later: k-3, k-2).  Residual loads are
+    // operations retire in order): the DMA of chunks k+1 .. k+PF-1 and the stores of the PF epilogues issued since
+    // (chunks k-PF .. k-1; with PIPE, whose epilogue runs one chunk later: k-PF-1 .. k-2).  Residual loads are
     // not counted: they have been consumed, and counting fewer only waits longer.
+    template <int N>
+    __device__ __forceinline__ void wait_le(int n) {      // s_waitcnt vmcnt(n) for a run-time n in [0, N]: the count is an immediate
+        if constexpr (N == 0) wait_vmcnt<0>();
+        else {
+            if (n >= N) wait_vmcnt<N>();
+            else wait_le<N - 1>(n);
+        }
+    }
     __device__ __forceinline__ void sync(int k) {
         constexpr int LAG = PIPE ? 1 : 0;
-        const bool d = k + 1 < nch, s1 = active && k >= 1 + LAG, s2 = active && k >= 2 + LAG;   // idle waves store nothing
-        if (d && s2) wait_vmcnt<PPW + 2 * MT>();
-        else if (d && s1) wait_vmcnt<PPW + MT>();
-        else if (d) wait_vmcnt<PPW>();
-        else if (s2) wait_vmcnt<2 * MT>();
-        else if (s1) wait_vmcnt<MT>();
-        else wait_vmcnt<0>();
+        int nd = 0, ns = 0;                                  // DMA batches / epilogues issued after chunk k's DMA (block-uniform but for `active`)
+#pragma unroll
+        for (int j = 1; j < PF; ++j) nd += (k + j < nch);
+#pragma unroll
+        for (int j = 1; j <= PF; ++j) ns += (active && k >= j + LAG);     // idle waves store nothing
+        // RES + PIPE: every step since has also requested its chunk's residual rows (MT loads, steps k-PF .. k-1); the
+        // newest of them are still in flight here and must be allowed to stay so
+        int nr = 0;
+        if (RES && PIPE) {
+#pragma unroll
+            for (int j = 1; j <= PF; ++j) nr += (active && k >= j);
+        }
+        // (a wave-uniform value: readfirstlane keeps the chain of compares scalar)
+        wait_le<(PF - 1) * PPW + PF * MT * ((RES && PIPE) ? 2 : 1)>(__builtin_amdgcn_readfirstlane(nd * PPW + (ns + nr) * MT));
 #ifdef VDX_STAMPS
         const unsigned long long t0 = WS_T();
 #endif
@@ -113,7 +138,7 @@ struct Ws {
 #ifdef VDX_STAMPS
         const unsigned long long t1 = WS_T();
 #endif
-        if (k + 2 < nch) issue(k + 2);    // into the ring slot chunk k-1 just vacated
+        if (k + PF < nch) issue(k + PF);  // into the ring slot chunk k-1 just vacated
 #ifdef VDX_STAMPS
         const unsigned long long t2 = WS_T();
         t_bar += t1 - t0;
@@ -193,13 +218,17 @@ struct Ws {
         }
     }
     // MFMAs of chunk k into `cur`, with the epilogue of chunk k-1 (from `prev`) spread between them
+    // rv_next (PIPE only): the residual set this step LOADS (chunk k's rows, for the epilogue that runs in the next step);
+    // the epilogue of chunk k-1 inside this step uses `rv`, the other set, requested one whole step ago.  Round 5
+    // requested chunk k-1's residual at the top of the step that stores it: ~1 450 of the chunk's 4 540 cycles were that
+    // load's latency (tools/ws_stamps.py: 4 542 against 3 090 without a residual).
+    typedef f16x8 Res[MT];
     template <bool HAS_PREV>
-    __device__ __forceinline__ void step(int k, Acc& cur, const Acc& prev) {
+    __device__ __forceinline__ void step(int k, Acc& cur, const Acc& prev, Res& rv_next, const Res& rv) {
         const char* st = smem + (k % NS) * STAGE + frow * 128;
-        f16x8 rv[MT];
-        if (RES && HAS_PREV) load_res(k - 1, rv);
         if (!active) zero(cur);
-        if (!active) return;
+        if (!active) return;              // (idle waves of a last panel: no loads either — their columns do not exist)
+        if (RES && PIPE) load_res(k, rv_next);
         if (WSET) {                                  // (block-uniform: every wave of the block walks the same chunks)
             if (set_left == 0) {
                 cur_set += 1;
@@ -222,10 +251,9 @@ struct Ws {
             }
         }
     }
-    __device__ __forceinline__ void drain(int k, const Acc& acc) {
+    __device__ __forceinline__ void drain(int k, const Acc& acc, Res& rv) {
         if (!active) return;
-        f16x8 rv[MT];
-        if (RES) load_res(k, rv);
+        if (RES && !PIPE) load_res(k, rv);            // (PIPE: chunk k's rows were requested by its own step)
 #pragma unroll
         for (int i = 0; i < MT; ++i) store_group(k, i, acc, rv);
     }
@@ -249,8 +277,9 @@ struct Ws {
         n0 = panel * (32 * NW) + wave * 32;
         active = n0 < p.N;
         a_src = p.a + (size_t)(lane >> 3) * p.lda + ((lane & 7) ^ (lane >> 3)) * 8;
-        issue(0);
-        if (nch > 1) issue(1);
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+            if (j < nch) issue(j);
 #ifdef VDX_STAMPS
         t_last = WS_T();
 #endif
@@ -267,30 +296,33 @@ struct Ws {
         for (int j = 0; j < 8; ++j) bv[j] = (f16)0.f;
         if (p.bias && active) bv = *(const f16x8*)(p.bias + n0 + 8 * fq);
 
+        Res r0, r1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) r0[i] = r1[i] = bv;         // (defined values for the paths that never load them)
         if (!PIPE) {
             for (int k = 0; k < nch; ++k) {
                 sync(k);
                 Acc acc;
-                step<false>(k, acc, acc);
-                drain(k, acc);
+                step<false>(k, acc, acc, r0, r0);
+                drain(k, acc, r0);
             }
         } else {
             Acc a, b;
             sync(0);
-            step<false>(0, a, a);
+            step<false>(0, a, a, r0, r1);
             int k = 1;
-            for (; k + 1 < nch; k += 2) {
+            for (; k + 1 < nch; k += 2) {  // odd chunks: accumulators b, residual set r1; even chunks: a, r0
                 sync(k);
-                step<true>(k, b, a);
+                step<true>(k, b, a, r1, r0);
                 sync(k + 1);
-                step<true>(k + 1, a, b);
+                step<true>(k + 1, a, b, r0, r1);
             }
             if (k < nch) {                 // nch even: chunk nch-1 goes into b, then drain b
                 sync(k);
-                step<true>(k, b, a);
-                drain(k, b);
+                step<true>(k, b, a, r1, r0);
+                drain(k, b, r1);
             } else {                       // nch odd: the last chunk is in a
-                drain(nch - 1, a);
+                drain(nch - 1, a, r0);
             }
         }
 #ifdef VDX_STAMPS
@@ -373,7 +405,7 @@ int vdx_gemm_ws_launch(const GemmP& p, int family, bool geglu, hipStream_t st) {
 // under the macros below; a library that carries one says so through vdx_build_flags() and vdx/_lib.py refuses to load it
 // as the product.
 extern "C" int vdx_lab_gemm_ws(void) {
-#if defined(VDX_STAMPS)
+#if defined(VDX_STAMPS) || defined(VDX_WS_NS3)
     return 2;
 #else
     return 0;

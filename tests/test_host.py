@@ -537,3 +537,19 @@ def test_network_emulation_sleeps_follow_the_reference():
     assert abs(emu_gather_delay_s(payload, both, random.Random(5)) - want) < 1e-12
     neg = DiffuserConfig(emu_rtt_ms=0.001, emu_jitter_ms=50.0)          # a negative draw sleeps 0, never a negative time
     assert min(emu_gather_delay_s(0, neg, random.Random(s)) for s in range(50)) == 0.0
+
+
+def test_ws_counted_waits_match_the_emitted_isa():
+    """csrc/gemm_ws.hip's `Ws::sync` waits with `s_waitcnt vmcnt(n)`, n = the DMA batches, epilogue stores and (round 6: residual
+    rows requested one step ahead) loads a wave has issued since the chunk it is about to read.  tools/ws_check_waits.py compares
+    the function totals of the emitted ISA with what the program structure issues, for every instantiation, and refuses any
+    scratch / buffer operation (scratch traffic counts in vmcnt: a spill would silently break the count)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ws_check_waits.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ws_check_waits: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok  ") >= 15 and "ring=4" in r.stdout

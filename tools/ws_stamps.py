@@ -48,3 +48,6 @@ run("L0 linear+res 320", M, 320, 320, res=True)
 run("Tin qkv 512->1536", M, 1536, 512)
 run("Tin geglu 512->4096", M, 4096, 512, geglu=True)
 run("L1 geglu 640->5120", M // 4, 5120, 640, geglu=True)
+run("L1 linear+res 640", M // 4, 640, 640, res=True)
+run("L1 linear 640", M // 4, 640, 640)
+run("L1 qkv 640->1920", M // 4, 1920, 640)
