@@ -106,3 +106,28 @@ def test_bare_bench_gpus_n_launches_itself(tmp_path):
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr or "rank: 1" in r.stderr, r.stderr[-2000:]
+
+
+def test_round6_bench_line_identifies_its_box_and_carries_a_parity_number():
+    """the line carries what identifies the box's speed (a fixed MFMA stream, a fixed copy, the shader
+    clock over the timed steps) and the HIP-vs-oracle distance at the benchmark's own spatial extent; the long-standing path
+    fields carry EXECUTED FLOPs.  Two committed lines from DIFFERENT boxes of the pool (raw step times 3.4 % apart) agree within
+    2 % once the step's TFLOP/s is divided by the box's probe."""
+    a = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_other_box.json")))
+    for d in (a, b):
+        box = d["box"]
+        for k in ("mfma_probe_tflops", "hbm_probe_gbs", "sclk_mhz_mean", "step_tflops_over_probe"):
+            assert k in box, k
+        assert 800 < box["mfma_probe_tflops"] < 2500 and 2000 < box["hbm_probe_gbs"] < 8000
+        assert box["sclk_mhz_mean"] is None or 500 < box["sclk_mhz_mean"] < 3000
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and 0 < cb["rel_l2_vs_hip"] < 4e-3
+        assert d["path_mfma_frac"] == d["path_mfma_frac_executed"] < d["path_mfma_frac_reference_equivalent"]
+        assert abs(d["path_tflops_per_gpu"] - d["tflop_per_step_executed"] * 1e3 / d["ms_per_step"]) < 0.01 * d["path_tflops_per_gpu"]
+        assert abs(box["step_tflops_over_probe"] - d["path_tflops_per_gpu"] / box["mfma_probe_tflops"]) < 1e-3
+        assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 0
+    assert abs(a["box"]["mfma_probe_tflops"] / b["box"]["mfma_probe_tflops"] - 1) > 0.02          # really two boxes
+    assert abs(a["ms_per_step"] / b["ms_per_step"] - 1) > 0.02
+    assert abs(a["box"]["step_tflops_over_probe"] / b["box"]["step_tflops_over_probe"] - 1) < 0.02
+    assert a["roofline"]["traffic"] is not None and a["hbm_traffic_bytes_per_step"] > 1e11        # the round's line has its PMC profile
