@@ -168,3 +168,49 @@ def test_native_rccl_entry_points_world_of_one(gpu):
     assert m.W.gathers > 10 and torch.equal(got, want)
     torch.cuda.synchronize()
     comm.destroy()
+
+
+@pytest.mark.gpu
+def test_side_stream_runs_beside_the_compute_stream(gpu):
+    """HIP maps streams onto a few hardware queues and two streams on one queue take turns; every 4th normal-priority stream
+    torch hands out shares the default (compute) stream's queue — with a NCCL process group alive, the first one (round 6,
+    profiles/r06_rccl_contention.md).  The store's side stream is a HIGH-priority stream, which has a queue of its own:
+    a 2 ms occupancy hog of one workgroup on it and 2 ms of GEMMs on the compute stream must take ~2 ms together, not 4 —
+    whichever of torch's pool streams the process has handed out before."""
+    import time
+    import vdx  # noqa: F401
+    from vdx import ops
+    from vdx.unet3d import UNet3DConditionModel, UNet3DConfig
+    from vdx.weights import synthetic_state_dict
+    burn = [torch.cuda.Stream(device=gpu) for _ in range(5)]          # move torch's round-robin pool on: the store must not care
+    cfg = UNet3DConfig(block_out_channels=(64, 128, 128, 128), cross_attention_dim=128, transformer_in_heads=2)
+    m = UNet3DConditionModel(cfg).load_diffusers_state_dict(synthetic_state_dict(cfg, seed=9, device=gpu), device=gpu).shard_(0, 1)
+    side = m.W._side
+    assert side.priority < 0, "the shard store's side stream must be a high-priority stream"
+    g = torch.Generator(device=gpu).manual_seed(0)
+    a = torch.randn(27648, 1280, device=gpu, dtype=torch.float16, generator=g)
+    w = torch.randn(1280, 1280, device=gpu, dtype=torch.float16, generator=g) * 0.03
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    def compute():
+        for _ in range(20):
+            ops.gemm(a, w, M=27648)
+    compute()
+    tc = min(timed(compute) for _ in range(3))
+
+    def both(stream):
+        def run():
+            ops.occupancy_hog(1, 0, int(tc * 1e3), stream)
+            compute()
+            stream.synchronize()
+        return min(timed(run) for _ in range(3))
+    t_side = both(side)
+    print(f"compute {tc:.2f} ms; with a {tc:.2f} ms hog on the store's side stream {t_side:.2f} ms")
+    assert t_side < 1.5 * tc, f"the side stream takes turns with the compute stream ({t_side:.2f} ms against {tc:.2f})"
+    del burn
