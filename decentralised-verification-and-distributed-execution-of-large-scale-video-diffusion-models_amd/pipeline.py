@@ -486,10 +486,13 @@ def run_job(cfg: DiffuserConfig, exchange: str = "allgather", out_video: Optiona
     from .compat.diffusers_shim import DiffusionPipeline
     from .compat import pynvml_shim
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1 and not dist.is_initialized():
+        # like the reference (:41-50): one process per GPU, backend "nccl" (= RCCL).  Rehearsal aids, never set by a real run:
+        # VDX_DIST_BACKEND=gloo + VDX_SHARE_GPU=1 let several ranks of a real multi-process job compute on ONE GPU
+        # (RCCL refuses two ranks per device), as `bench.py --backend gloo --share-gpu` does.
         from .shard import configure_rccl_env
         configure_rccl_env()
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(0 if os.environ.get("VDX_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group(os.environ.get("VDX_DIST_BACKEND", "nccl"))
     dev = torch.device(cfg.device if cfg.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
     if pipe is None:
         pipe = DiffusionPipeline.from_pretrained(cfg.model_id, torch_dtype=torch.float16, low_cpu_mem_usage=True,

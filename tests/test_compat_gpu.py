@@ -89,3 +89,27 @@ def test_front_end_writes_the_reference_csv_row(gpu, tmp_path):
     # 0.3 s (gauss(300, 0)) + 0.3 s before the reduction + payload / (0.001 Mbps) = 80 B / 125 B/s = 0.64 s
     assert emu_s - plain_s > 1.0, (plain_s, emu_s)
     assert os.path.getsize(mp4) > 1000
+
+
+def test_front_end_two_ranks_under_torchrun(gpu, tmp_path):
+    """The front end as the reference's sweep script launches its own (`torchrun --nproc_per_node=2 …`, full_experiments_ZeroscopeXL.sh):
+    two real processes (both on this box's one GPU: gloo + VDX_SHARE_GPU, rehearsal aids), `--mode hybrid_ctx`: parameters sharded
+    1/2 per rank, ctx broadcast, one window per rank, all-gather + blend, rank 0 writes the row."""
+    import csv
+    out_csv, mp4 = str(tmp_path / "r2.csv"), str(tmp_path / "o2.mp4")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(VDX_DIST_BACKEND="gloo", VDX_SHARE_GPU="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", "-m", "vdx.pipeline", "--model_id", "synthetic:tiny", "--num_frames", "12", "--steps", "2",
+                        "--height", "128", "--width", "256", "--overlap", "2", "--mode", "hybrid_ctx", "--out_csv", out_csv,
+                        "--out_video", mp4, "--noise_device", "cpu", "--emu_rtt_ms", "10"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rows = list(csv.DictReader(open(out_csv)))
+    assert len(rows) == 1 and int(rows[0]["world_size"]) == 2 and rows[0]["mode"] == "hybrid_ctx"
+    import vdx  # noqa: F401
+    from vdx.planner import plan
+    cp = plan(12, 2, 0, 2)
+    assert (int(rows[0]["chunk_size"]), int(rows[0]["overlap"])) == (cp.chunk, cp.overlap)
+    assert int(rows[0]["network_bytes"]) == sum((e - s) * 4 * 2 for s, e in cp.for_rank(0))          # rank 0's own chunk list (:194)
+    assert rows[0]["temp_instab"] != "" and os.path.getsize(mp4) > 1000
