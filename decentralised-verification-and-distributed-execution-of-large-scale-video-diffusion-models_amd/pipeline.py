@@ -534,7 +534,8 @@ def run_job(cfg: DiffuserConfig, exchange: str = "allgather", out_video: Optiona
     return {"world_size": d.world, "chunk_size": info["chunk_size"], "overlap": info["overlap"], "num_frames": cfg.num_frames,
             "peak_vram_mb": peak_mb, "end_vram_mb": int(end_mb), "network_bytes": int(info["payload_bytes"]),
             "net_gather_s": info["net_gather_s"], "net_reduce_s": reduce_s, "temp_instab": temp_instab, "flow_err": flow_err,
-            "denoise_s": info["denoise_s"], "exchange": exchange, "rank": d.rank, "synthetic_weights": pipe.synthetic_weights}
+            "denoise_s": info["denoise_s"], "exchange": exchange, "rank": d.rank, "synthetic_weights": pipe.synthetic_weights,
+            "emu_gather_delay_s": info["emu_gather_delay_s"], "emu_reduce_delay_s": delay}
 
 
 def main(argv=None) -> int:
