@@ -378,8 +378,8 @@ def main():
             # blit kernel on the GPU that is computing; on a node 7 of 8 are remote pulls.  An upper bound of the cost.)
             unet.W.rehearse_copies = args.as_world
         if args.hog:
-            if not (args.rehearse_dist and args.as_world > 1 and world == 1):
-                raise SystemExit("--hog is a one-GPU rehearsal aid: use it with --rehearse-dist --as-world N")
+            if not (args.rehearse_dist and args.as_world > 1 and world == 1) or args.resident:
+                raise SystemExit("--hog is a one-GPU rehearsal aid of the SHARDED store: use it with --rehearse-dist --as-world N, without --resident")
             unet.W.rehearse_hog = (args.hog, 64 << 10, args.hog_gbs, args.as_world)
         if args.reserve_cus >= 0:
             if not args.rehearse_dist:

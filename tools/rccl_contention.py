@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--gbs", type=float, default=100.0, help="modelled all-gather rate per GPU (GB/s) at >= 8 channels")
     ap.add_argument("--as-world", type=int, default=8)
+    ap.add_argument("--only", default=None, help="run only the configurations whose label contains this text (for a rocprofv3 kernel trace)")
     args = ap.parse_args()
     os.environ["VDX_SHARD_FORCE_COLLECTIVE"] = "1"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -80,6 +81,8 @@ def main():
                ("R=8 held", 8, g, 0), ("R=8 held, reserve 8", 8, g, 8),
                ("R=16 held", 16, g, 0), ("R=16 held, reserve 16", 16, g, 16),
                ("R=32 held", 32, g, 0), ("R=32 held, reserve 32", 32, g, 32)]
+    if args.only:
+        configs = [c for c in configs if c[1] == 0 and c[3] == 0] + [c for c in configs if args.only in c[0]]
     times = {c[0]: [] for c in configs}
     lat = lat0
     for i in range(2):
