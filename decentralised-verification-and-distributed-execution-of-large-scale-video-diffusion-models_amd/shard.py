@@ -121,7 +121,7 @@ class ShardedStore:
         `torch.distributed`.  `transport`: "collective" | "peer" (module docstring); default from VDX_SHARD_TRANSPORT,
         else "collective".  `merge_bytes`: neighbours of the schedule are gathered TOGETHER while their sum stays within
         this many bytes (fewer, larger transfers: the level-0 / level-1 units of the XL UNet are 2-18 MB each and a gather
-        is `world` copies or one collective whatever its size); the two gather buffers are sized by the largest unit
+        is `world` copies or one collective whatever its size); the gather buffers are sized by the largest unit
         anyway (95 MB), so merging below that costs no memory.  0 = one gather per unit."""
         self.rank, self.world, self.group, self.comm = rank, world, group, comm
         if merge_bytes > 0:
