@@ -486,8 +486,15 @@ static int choose_split(int begin, int end, int N) {
     if (whole.v != 2 && !(nt320 * 320 * 4 <= N * 5 && rows >= 1024)) return 0;
     const long long t256 = ((rows + 255) / 256) * nt320;
     const long long full = t256 / 256;
-    if (full == 0 || t256 % 256 == 0) return 0;
-    const long long mt_main = full * 256 / nt320;                 // m tiles of the main launch (<= `full` rounds)
+    // The main launch is EXACT-FIT: `full` rounds of one tile per CU.  Beside a collective whose channel kernels hold a few CUs
+    // (a multi-GPU run) it runs a whole round more: +12...+38 % on the 100 launches of exactly 256 tiles a 16-frame window has
+    // (profiles/r06_rccl_contention.md, section 2b).  With a reserve in force (vdx_set_reserved_cus; 0 on one GPU: nothing
+    // changes) a round of the main launch fills only the unreserved CUs and the tail takes the rows that are left.  Everything
+    // else stays priced on the full chip: pricing ALL rounds on the reserved count changes tile families everywhere (+6.5 %).
+    const long long nc = vdx_grid_cus() < 256 ? vdx_grid_cus() : 256;
+    if (full == 0 || (t256 % 256 == 0 && nc == 256)) return 0;
+    const long long mt_main = full * nc / nt320;                  // m tiles of the main launch (<= `full` rounds)
+    if (mt_main == 0) return 0;
     const int split = begin + (int)(mt_main * 256);
     if (split >= end) return 0;
     const TileChoice tail = choose_tile(end - split, N);

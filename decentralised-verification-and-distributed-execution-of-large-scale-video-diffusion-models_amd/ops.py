@@ -817,6 +817,7 @@ def set_reserved_cus(n: int) -> int:
     Returns the CU count the persistent grids now fill."""
     lib = _lib.load()
     _lib.check(lib.vdx_set_reserved_cus(int(n)), "vdx_set_reserved_cus")
+    _PLAN_CACHE.clear()          # the tiled GEMM's split rows depend on the reserve (vdx_gemm_plan: rounds of the unreserved CUs)
     return lib.vdx_persistent_grid_cus()
 
 

@@ -44,16 +44,19 @@ import torch.distributed as dist
 
 ALIGN = 64          # elements: keeps every view 128-byte aligned
 
-# RCCL's all-gather runs as `nchannels` workgroups, each holding a compute unit for the duration of the collective, and the
-# weights-stationary GEMMs and K5 / K7 / K8 launch ONE workgroup per CU with up to 160 KB of LDS: beside a gather an exact-fit
-# grid leaves its displaced workgroups to a second round.  Round 6 PRICED that on one GPU (tools/rccl_contention.py,
-# profiles/r06_rccl_contention.md: an occupancy hog of R workgroups behind every gather for the time a ring all-gather of
-# the group's remote bytes takes): holding 1, 8, 16 or 32 CUs costs the SAME (+7 % of a 16-frame window at 100 GB/s: what the
-# gathers' DURATION exposes, not what they hold — the bytes sit at the 1280-channel levels, the persistent grids at levels
-# 0-1, and a grid that finds 16 CUs taken loses a third, not half), and a reserve of R CUs costs more (+1 %) than it saves.
-# Halving the gather RATE (4 channels at 50 GB/s) costs +18 %.  Hence: no channel cap (RCCL picks what moves bytes fastest),
-# no reserve by default (`vdx_set_reserved_cus` stays available: VDX_RESERVED_CUS), and the two things that DID matter:
-# the side stream on a hardware queue of its own (`_side` below: -18 ms) and prefetch depth 2 (`prefetch_depth`).
+# RCCL's all-gather runs as `nchannels` workgroups, each holding a compute unit for the duration of the collective.  Round 6
+# PRICED that on one GPU (tools/rccl_contention.py, tools/trace_hog_diff.py, profiles/r06_rccl_contention.md: an occupancy hog of
+# R workgroups behind every gather for the time a ring all-gather of the group's remote bytes takes):
+#   * holding 1, 8, 16 or 32 CUs costs the SAME, +6 % of a 16-frame window at 100 GB/s: ~2 ms of exposed gathers + ~4-5 ms of
+#     SECOND ROUNDS in the tiled GEMM, whose planner covers a level-1/2 product with whole rounds of one tile per CU — ONE held CU
+#     turns a round into two (the persistent exact-fit grids sit at levels 0-1, where the gathers are short);
+#   * `vdx_set_reserved_cus(r)` — persistent grids AND those main launches fill only the unreserved CUs — takes it to +3.4 % when
+#     r >= the CUs held and r <= 16, costs +0.5 % when nothing is held, and buys nothing when r is smaller than what is held;
+#   * halving the gather RATE (4 channels at 50 GB/s) costs +17 %.
+# The right r is RCCL's channel count on a node, which no run of this build has seen (32+ by default: no reserve helps, and the
+# gathers are shorter than modelled).  Hence the DEFAULTS: no channel cap, reserve 0 — both environment knobs for the first node
+# run (NCCL_MAX_NCHANNELS=16 VDX_RESERVED_CUS=16 is the pair to try) — and the two things that mattered unconditionally: the side
+# stream on a hardware queue of its own (`_side` below: -18 ms) and prefetch depth 2 (`prefetch_depth`).
 
 
 def configure_rccl_env(env=None):
@@ -66,8 +69,8 @@ def configure_rccl_env(env=None):
 
 
 def reserved_cus_for(world: int, transport: str) -> int:
-    """CUs the persistent grids leave to a collective's channel kernels: VDX_RESERVED_CUS for a world > 1 on the collective
-    transport, else 0 (default 0: measured not to pay, see above)."""
+    """CUs the persistent grids and the tiled GEMM's exact-fit main launches leave to a collective's channel kernels:
+    VDX_RESERVED_CUS for a world > 1 on the collective transport, else 0 (default 0: see above)."""
     if world <= 1 or transport != "collective":
         return 0
     return int(os.environ.get("VDX_RESERVED_CUS", "0"))

@@ -336,12 +336,14 @@ int vdx_halo_exchange(vdx_comm* comm, const void* send_buf, size_t send_bytes, i
                       size_t recv_bytes, int recv_from, vdx_stream_t side_stream);
 
 /* ------------------------------------------------------------------------------------------
- * Persistent grids and the CUs a collective holds.  The weights-stationary GEMMs and the fused sub-block kernels (K5, K7,
- * K8) launch one workgroup per compute unit.  While a parameter gather (fsdp_chunked_coherent.py:63-88's FSDP all-gather;
- * here RCCL on a side stream) runs beside the step, each of its channel kernels holds a CU; an exact-fit grid then runs
- * its displaced workgroups as a second round.  `vdx_set_reserved_cus(r)` makes every persistent grid leave r CUs free
- * (rounded so the grid stays a multiple of 8 = the XCD count); results do not depend on r, bit for bit.  Process-wide,
- * not thread-safe against concurrent launches; the shard store sets it once when world > 1 (vdx/shard.py).            */
+ * Exact-fit grids and the CUs a collective holds.  The weights-stationary GEMMs and the fused sub-block kernels (K5, K7,
+ * K8) launch one workgroup per compute unit, and vdx_gemm_plan covers a product with whole rounds of one 256x320 tile per
+ * CU + a tail.  While a parameter gather (fsdp_chunked_coherent.py:63-88's FSDP all-gather; here RCCL on a side stream)
+ * runs beside the step, each of its channel kernels holds a CU, and an exact-fit launch then runs a whole round more.
+ * `vdx_set_reserved_cus(r)` makes every persistent grid and every such main launch leave r CUs free per round (rounded so
+ * the grid stays a multiple of 8 = the XCD count; the tail launch takes the rows left over); results do not depend on r,
+ * bit for bit.  Process-wide, not thread-safe against concurrent launches; a caller that caches vdx_gemm_plan's answers
+ * must drop them when r changes (vdx/ops.py does).  Default 0; vdx/shard.py sets VDX_RESERVED_CUS for a world > 1.       */
 int vdx_set_reserved_cus(int n);
 int vdx_reserved_cus(void);
 int vdx_persistent_grid_cus(void);

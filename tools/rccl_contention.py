@@ -76,11 +76,12 @@ def main():
     configs = [("no collective (world-1 rehearsal as before)", 0, g, 0),
                ("no collective, grids reserve 8", 0, g, 8),
                ("no collective, grids reserve 16", 0, g, 16),
-               ("R=1 held (the gather's DURATION alone)", 1, g, 0),
+               ("R=1 held (the gather's DURATION alone)", 1, g, 0), ("R=1 held, reserve 8", 1, g, 8),
                ("R=4 held", 4, g / 2, 0), ("R=4 held, reserve 8", 4, g / 2, 8),
                ("R=8 held", 8, g, 0), ("R=8 held, reserve 8", 8, g, 8),
                ("R=16 held", 16, g, 0), ("R=16 held, reserve 16", 16, g, 16),
-               ("R=32 held", 32, g, 0), ("R=32 held, reserve 32", 32, g, 32)]
+               ("R=32 held", 32, g, 0), ("R=32 held, reserve 32", 32, g, 32),
+               ("R=16 held, reserve 8", 16, g, 8), ("R=32 held, reserve 16", 32, g, 16), ("R=8 held, reserve 16", 8, g, 16)]
     if args.only:
         configs = [c for c in configs if c[1] == 0 and c[3] == 0] + [c for c in configs if args.only in c[0]]
     times = {c[0]: [] for c in configs}

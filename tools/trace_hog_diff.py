@@ -40,4 +40,20 @@ diff = sorted(((hby[k][1] - pby.get(k, [0, 0.0])[1], k) for k in hby), reverse=T
 print(f"{'kernel':62s} launches   plain us     hog us    diff us")
 for d, k in diff[:25]:
     print(f"{k:62s} {hby[k][0]:6d} {pby.get(k, [0, 0.0])[1]:10.1f} {hby[k][1]:10.1f} {d:10.1f}")
+# the tiled GEMM by grid size (tiles = workgroups): which launches pay?
+def by_grid(st):
+    d = defaultdict(lambda: [0, 0.0])
+    for r in st[2]:
+        if "gemm_kernel<256, 320" in r["Kernel_Name"]:
+            tiles = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) // (int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1))
+            k = (r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", ""), tiles)
+            d[k][0] += 1
+            d[k][1] += (r["e"] - r["s"]) / 1e3
+    return d
+pg, hg = by_grid(plain[-1]), by_grid(hog[-1])
+print(f"\n{'tiled GEMM instantiation':34s} tiles  rounds launches  plain us/launch  hog us/launch   diff")
+for k in sorted(hg, key=lambda k: -(hg[k][1] - pg.get(k, [0, 0.0])[1])):
+    n = hg[k][0]
+    p_ = pg.get(k, [n, 0.0])[1] / max(pg.get(k, [n, 0.0])[0], 1)
+    print(f"{k[0]:34s} {k[1]:5d} {k[1] / 256:7.3f} {n:7d} {p_:14.1f} {hg[k][1] / n:14.1f} {100 * (hg[k][1] / n / max(p_, 1e-9) - 1):+6.1f} %")
 print(f"sum of positive differences {sum(d for d, _ in diff if d > 0) / 1e3:.2f} ms, of all {sum(d for d, _ in diff) / 1e3:.2f} ms")
