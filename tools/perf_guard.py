@@ -2,9 +2,10 @@
 """Per-launch time guard for the dominant kernels (an 11 % regression of the 3x3-conv kernel went unnoticed for
 half a round).  Compares the rocprofv3 --kernel-trace --stats averages of a fresh run with a committed profile and FAILS
 (exit 1) when a guarded kernel's average launch got more than --tol (4 %) slower than the BOX, or 2 x tol outright.  Boxes
-of the pool differ by several per cent as a whole.  The box factor is the ratio of the two runs' MFMA PROBES when both bench
-lines carry one (`box.mfma_probe_tflops`, round 6: a fixed instruction stream measured in the bench process — independent
-of the kernels being judged); without probes, the median ratio of the guarded kernels (rounds 4-5).
+of the pool differ by several per cent as a whole.  Two box factors: the median ratio of the guarded kernels (rounds 4-5) and,
+when both bench lines carry one, the ratio of the two runs' MFMA PROBES (`box.mfma_probe_tflops`, round 6: a fixed instruction
+stream measured in the bench process — independent of the kernels being judged); a kernel fails when it is slower than the box
+by BOTH (the probe alone mispredicted a box by ~3 % in round 6).
 
     python tools/perf_guard.py gpurun_out/rNN/kernel_stats.csv profiles/r03_kernel_stats.csv [--tol 0.04]
                                [--bench-new gpurun_out/rNN/bench.json --bench-ref profiles/r0M_bench.json]"""
@@ -69,19 +70,25 @@ def main():
     ratios = sorted(tn / tr for _, tn, tr, _, _, ok in rows if ok)
     box = ratios[len(ratios) // 2] if ratios else 1.0
     probes = [probe_of(a.bench_new), probe_of(a.bench_ref)]
+    box_p = None
     if all(probes):
-        print(f"  box factor from the MFMA probes (reference {probes[1]:.1f} / new {probes[0]:.1f} TFLOP/s): {probes[1] / probes[0]:.3f}"
-              f"   [median ratio of the guarded kernels: {box:.3f}]")
-        box = probes[1] / probes[0]
+        # A kernel fails only when it is slower than the box by BOTH measures: the probe is independent of the kernels judged
+        # but is one instruction stream (round 6: two boxes whose probes said 0.990 ran every kernel 1-3.6 % apart the other
+        # way — HBM and clocks under mixed load differ too); the median moves with a uniform regression.  Either alone misjudges.
+        box_p = probes[1] / probes[0]
+        print(f"  box factor from the MFMA probes (reference {probes[1]:.1f} / new {probes[0]:.1f} TFLOP/s): {box_p:.3f};  "
+              f"median ratio of the guarded kernels: {box:.3f}")
     else:
         print(f"  box factor (median ratio of the guarded kernels; no MFMA probe in {'either' if not any(probes) else 'one'} bench line): {box:.3f}")
     bad = 0
     for g, tn, tr, cn, cr, ok in rows:
         raw, rel = tn / tr - 1.0, tn / tr / box - 1.0
-        fail = ok and (rel > a.tol or raw > 2 * a.tol)
+        rel_p = tn / tr / box_p - 1.0 if box_p else rel
+        fail = ok and ((rel > a.tol and rel_p > a.tol) or raw > 2 * a.tol)
         bad += fail
         note = "" if ok else f"  (calls {cn} vs {cr}: shape mix differs, not judged)"
-        print(f"  {g:58s} {tn / 1e3:9.1f} us vs {tr / 1e3:9.1f} us  {100 * raw:+6.1f} %  vs box {100 * rel:+6.1f} %  {'FAIL' if fail else 'ok'}{note}")
+        vs_p = f"  vs probe {100 * rel_p:+6.1f} %" if box_p else ""
+        print(f"  {g:58s} {tn / 1e3:9.1f} us vs {tr / 1e3:9.1f} us  {100 * raw:+6.1f} %  vs box {100 * rel:+6.1f} %{vs_p}  {'FAIL' if fail else 'ok'}{note}")
     if bad:
         print(f"perf_guard: {bad} guarded kernel(s) more than {100 * a.tol:.0f} % slower than {a.ref} (box-normalised; or {200 * a.tol:.0f} % outright)")
         sys.exit(1)
