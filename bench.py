@@ -138,8 +138,7 @@ def box_probe(dev):
     the timed region (~0.2 s): the boxes of the pool differ by several per cent as a whole (BENCH_r05 ran every kernel 7-9 %
     slower than the builder's box on unchanged sources), and a line without this cannot tell a slower part from a slower build.
       mfma_probe_tflops  `vdx_probe_mfma_f16`: dense v_mfma_f32_32x32x16_f16, two waves per SIMD, per-lane operands, every CU
-                         (main() takes it again right behind the timed steps — the part as warm as the steps saw it — and
-                         keeps this first, cold reading as mfma_probe_tflops_cold)
+                         (main() takes it again right behind the timed steps as mfma_probe_tflops_after_steps: reported, not used)
       hbm_probe_gbs      1 GiB device-to-device copy (read + write bytes / time, median of 3)
     `tools/perf_guard.py` and a reader normalise `ms_per_step` by mfma_probe_tflops (the step is MFMA-bound by arithmetic)."""
     from vdx import ops
@@ -461,12 +460,12 @@ def main():
     if sclk is not None:
         box.update(sclk.stop())
     if rank == 0:
-        # the probe again, right behind the timed steps (outside them): the part in the thermal / clock state the steps ran in.
-        # The one taken before the warm-up sees a cold part and read 2-4 % higher on the same box (round 6); this is the one to
-        # normalise by, the cold one is kept beside it.
+        # The probe once more right behind the timed steps, REPORTED ONLY: round 6 measured it on five boxes — it reads 1 453 to
+        # 1 751 TFLOP/s (a sustained dense-MFMA stream runs into each part's power limit, 1.39-1.67 GHz) while the step differs by
+        # 4.5 %, so it does not predict the step.  The reading BEFORE the warm-up (a short burst on a part that has just synthesised
+        # and packed the weights) does: executed TFLOP/s over it is 0.640-0.647 on all five (profiles/r06_box_probe.md).
         from vdx import ops as _ops
-        box["mfma_probe_tflops_cold"] = box.get("mfma_probe_tflops")
-        box["mfma_probe_tflops"] = round(_ops.probe_mfma(dev), 1)
+        box["mfma_probe_tflops_after_steps"] = round(_ops.probe_mfma(dev), 1)
     g1, h1 = (store.gathers, store.gather_host_s) if store is not None else (0, 0.0)
     ops.PROFILE = None
     finite = all(bool(torch.isfinite(lat.float()).all()) for lat in lats)
