@@ -213,3 +213,33 @@ def test_groupnorm_at_9216_rows_per_frame(gpu, ns, Fr, c1, c2):
     out = ops.groupnorm(x1, gamma.half().to(gpu), beta.half().to(gpu), groups=32, n_samples=ns, rows_per_sample=rps,
                         eps=1e-5, silu_act=True, x2=x2)
     close(out, ref, tol=4e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (c) the step right after the path at its full extent: one 576x1024 frame through the VAE decoder (:219-225)
+# ---------------------------------------------------------------------------------------------------------------
+def test_vae_decode_one_full_size_frame_matches_oracle_live(gpu):
+    """`vae.decode(z / 0.18215).sample` for ONE frame of the headline video — a 72x128 latent to 576x1024 RGB, Stable-Diffusion
+    widths, the mid block's single attention head over 9 216 tokens — against the fp32 oracle on the host cores, and the uint8
+    frame the reference would write (:224-225) against the oracle's to one grey level."""
+    import numpy as np
+    import vdx  # noqa: F401
+    from vdx.vae import AutoencoderKL, VaeConfig
+    from oracle import vae_ref
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    cfg = vae_ref.VaeConfig.sd()
+    sd16 = {k: v.half() for k, v in vae_ref.synthetic_state_dict(cfg, seed=2).items()}
+    ref = vae_ref.AutoencoderKLRef(cfg).eval()
+    ref.load_state_dict({k: v.float() for k, v in sd16.items()})
+    m = AutoencoderKL(VaeConfig.sd()).load_diffusers_state_dict(sd16, device=gpu)
+    z = torch.randn(1, 4, H, W, generator=torch.Generator().manual_seed(72)).half()
+    with torch.no_grad():
+        want = ref.decode(z.float()).sample
+    got = m.decode(z.to(gpu)).sample
+    err = rel_l2(got.float().cpu(), want)
+    print(f"vae SD widths, one 72x128 latent -> 576x1024: rel-L2 {err:.3e}, out std {float(want.std()):.3f}")
+    assert got.shape == (1, 3, 8 * H, 8 * W) and err <= 4e-3
+    u8 = m.decode_frames_u8(z.to(gpu)).cpu().numpy()[0]
+    want_u8 = ((want[0].permute(1, 2, 0) * 0.5 + 0.5).clamp(0, 1) * 255).byte().numpy()
+    diff = np.abs(u8.astype(np.int32) - want_u8.astype(np.int32))
+    assert u8.shape == (8 * H, 8 * W, 3) and diff.max() <= 3 and (diff <= 1).mean() > 0.995
