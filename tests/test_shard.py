@@ -61,18 +61,18 @@ print("rank", rank, "ok", st.gathers)
 """
 
 
-@pytest.mark.parametrize("arena_bytes,min_arenas,depth", [(256 << 20, 1, 2), (1 << 20, 4, 1), (1 << 20, 4, 3)],
-                         ids=["one-arena-depth2", "many-arenas-depth1", "many-arenas-depth3"])
-def test_shard_store_two_ranks_gloo(tmp_path, arena_bytes, min_arenas, depth):
+@pytest.mark.parametrize("arena_bytes,min_arenas,depth,world", [(256 << 20, 1, 2, 2), (1 << 20, 4, 1, 2), (1 << 20, 4, 3, 2), (1 << 20, 3, 2, 3)],
+                         ids=["one-arena-depth2", "many-arenas-depth1", "many-arenas-depth3", "three-ranks-depth2"])
+def test_shard_store_two_ranks_gloo(tmp_path, arena_bytes, min_arenas, depth, world):
     """`many-arenas`: the cap lowered to 1 MB so that the tiny model's shards spread over several arenas — the layout the XL
     model has at its 256 MB cap (an exported allocation must stay under 1 GiB: vdx/shard.py)."""
     script = tmp_path / "shard.py"
     script.write_text(GLOO_SCRIPT.format(root=ROOT, arena_bytes=arena_bytes, min_arenas=min_arenas, depth=depth))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 def test_unit_map_covers_every_packed_tensor():
