@@ -2,7 +2,6 @@
 """Launch time of the tiled 256x320 GEMM against the tile count around whole rounds of 256 (is an exact-fit grid a cliff?)."""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
